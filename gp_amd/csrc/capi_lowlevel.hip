@@ -1,0 +1,56 @@
+// capi_lowlevel.hip — device-memory helpers and the low-level dense entry points of the C ABI.
+#include "gpx_internal.h"
+#include "../../include/gpx.h"
+
+extern "C" {
+
+int gpx_device_count(int* n) {
+    HIP_TRY(hipGetDeviceCount(n));
+    return GPX_OK;
+}
+int gpx_set_device(int dev) {
+    HIP_TRY(hipSetDevice(dev));
+    return GPX_OK;
+}
+int gpx_malloc(void** p, int64_t bytes) {
+    HIP_TRY(hipMalloc(p, (size_t)(bytes > 0 ? bytes : 1)));
+    return GPX_OK;
+}
+int gpx_free(void* p) {
+    HIP_TRY(hipFree(p));
+    return GPX_OK;
+}
+int gpx_memcpy_h2d(void* dst, const void* src, int64_t bytes) {
+    HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+    return GPX_OK;
+}
+int gpx_memcpy_d2h(void* dst, const void* src, int64_t bytes) {
+    HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return GPX_OK;
+}
+int gpx_memset_zero(void* dst, int64_t bytes) {
+    HIP_TRY(hipMemset(dst, 0, (size_t)bytes));
+    return GPX_OK;
+}
+int gpx_device_synchronize(void) {
+    HIP_TRY(hipDeviceSynchronize());
+    return GPX_OK;
+}
+
+int gpx_dgemm(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+              int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int flags) {
+    if (!A || !B || !C || M < 0 || N < 0 || K < 0) return GPX_ERR_ARG;
+    if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N) || ldc < M) return GPX_ERR_ARG;
+    return gpx_gemm(0, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags);
+}
+
+int gpx_dgemm_splitk(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+                     int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
+                     int flags, double* work, int64_t work_doubles) {
+    if (!A || !B || !C || M < 0 || N < 0 || K < 0) return GPX_ERR_ARG;
+    if (lda < (a_kc ? K : M) || ldb < (b_kc ? K : N) || ldc < M) return GPX_ERR_ARG;
+    return gpx_gemm_splitk(0, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, work,
+                           work_doubles);
+}
+
+}  // extern "C"

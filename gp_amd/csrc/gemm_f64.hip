@@ -1,0 +1,284 @@
+// gemm_f64.hip — fp64 GEMM on the CDNA4 matrix cores (v_mfma_f64_16x16x4_f64), gfx950 only.
+//
+// One kernel serves every dense contraction of the GP path (Cholesky trailing SYRK/GEMM, the
+// triangular inverse, W^T W, the tall-skinny FITC/VFE products): C = alpha*op(A)*op(B)^T + beta*C,
+// column-major, either operand M/N-contiguous or K-contiguous, optional lower-triangle-only
+// output and per-tile K ranges that skip the zero half of triangular operands.
+//
+// Layout of one workgroup: 256 threads = 4 waves in a 2(M) x 2(N) grid, block tile
+// (32*TM) x (32*TN) with BK = 16; each wave owns TM x TN MFMA tiles of 16x16 (4x4 -> 64x64 per
+// wave, 128 accumulator VGPRs).  Operand tiles go global -> registers (prefetch of the next K
+// tile is in flight while the current one is multiplied) -> LDS -> one f64 per lane per MFMA.
+// The MFMA's "A" operand is fed from matrix B and its "B" operand from matrix A, so that the
+// lane index (lane & 15) runs along M: accumulator stores and the beta*C read are 128-B
+// contiguous per 16 lanes in the column-major C.
+#include "gpx_internal.h"
+
+namespace {
+
+struct GemmArgs {
+    const double* A;
+    const double* B;
+    double* C;
+    long lda, ldb, ldc;
+    int M, N, K;
+    double alpha, beta;
+    int flags;
+    int tiles_m, tiles_n, ntiles;
+    int splitk;
+    long slab;     // doubles between split-K slabs
+    int fastA, fastB;  // base pointer and ld allow 16-B vector loads
+};
+
+constexpr int BK = 16;
+
+// global -> registers: BMN*BK doubles per operand tile, BMN/32 double2 per thread
+template <int BMN, bool KC>
+__device__ __forceinline__ void gload(const double* __restrict__ P, long ld, int mn0, int k0, int MN,
+                                      int kend, bool fast, v2d (&r)[BMN / 32]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < BMN / 32; ++i) {
+        const int e = tid + 256 * i;
+        if (!KC) {
+            const int m = mn0 + 2 * (e % (BMN / 2));
+            const int k = k0 + e / (BMN / 2);
+            const double* p = P + m + (long)k * ld;
+            if (fast) {
+                r[i] = *reinterpret_cast<const v2d*>(p);
+            } else {
+                const bool kin = k < kend;
+                r[i].x = (kin && m < MN) ? p[0] : 0.0;
+                r[i].y = (kin && m + 1 < MN) ? p[1] : 0.0;
+            }
+        } else {
+            const int k = k0 + 2 * (e % 8);
+            const int m = mn0 + e / 8;
+            const double* p = P + k + (long)m * ld;
+            if (fast) {
+                r[i] = *reinterpret_cast<const v2d*>(p);
+            } else {
+                const bool min_ = m < MN;
+                r[i].x = (min_ && k < kend) ? p[0] : 0.0;
+                r[i].y = (min_ && k + 1 < kend) ? p[1] : 0.0;
+            }
+        }
+    }
+}
+
+// registers -> LDS.  M-contiguous image: [BK][BMN+16] (row stride = 128 B mod 256 B, so the four
+// k-rows one MFMA fragment read touches fall on disjoint banks); K-contiguous image: [BMN][BK+2]
+// (row stride 144 B = 16*9: sixteen consecutive rows cover all 16-B bank slots once).
+template <int BMN, bool KC>
+__device__ __forceinline__ void sstore(double* __restrict__ s, const v2d (&r)[BMN / 32]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < BMN / 32; ++i) {
+        const int e = tid + 256 * i;
+        if (!KC) {
+            const int m2 = e % (BMN / 2), k = e / (BMN / 2);
+            *reinterpret_cast<v2d*>(&s[k * (BMN + 16) + 2 * m2]) = r[i];
+        } else {
+            const int k2 = e % 8, m = e / 8;
+            *reinterpret_cast<v2d*>(&s[m * (BK + 2) + 2 * k2]) = r[i];
+        }
+    }
+}
+
+template <int BMN, bool KC>
+__device__ __forceinline__ double sfrag(const double* __restrict__ s, int row, int k) {
+    return KC ? s[row * (BK + 2) + k] : s[k * (BMN + 16) + row];
+}
+
+template <int TM, int TN, bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+    constexpr int BM = 32 * TM, BN = 32 * TN;
+    constexpr int LA = AKC ? BM * (BK + 2) : BK * (BM + 16);
+    constexpr int LB = BKC ? BN * (BK + 2) : BK * (BN + 16);
+    __shared__ __attribute__((aligned(16))) double smem[LA + LB];
+    double* sA = smem;
+    double* sB = smem + LA;
+
+    int tile = blockIdx.x, ks = 0;
+    if (g.splitk > 1) {
+        ks = tile % g.splitk;
+        tile /= g.splitk;
+    }
+    if (g.flags & GEMM_HEAVY_LAST) tile = g.ntiles - 1 - tile;
+    int bi, bj;
+    if (g.flags & GEMM_LOWER) {
+        bi = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+        while (bi * (bi + 1) / 2 > tile) --bi;
+        while ((bi + 1) * (bi + 2) / 2 <= tile) ++bi;
+        bj = tile - bi * (bi + 1) / 2;
+    } else {
+        bi = tile % g.tiles_m;
+        bj = tile / g.tiles_m;
+    }
+    const int m0 = bi * BM, n0 = bj * BN;
+
+    int klo = 0, khi = g.K;
+    if (g.flags & GEMM_KLO_M) klo = max(klo, m0);
+    if (g.flags & GEMM_KLO_N) klo = max(klo, n0);
+    if (g.flags & GEMM_KHI_M) khi = min(khi, m0 + BM);
+    if (g.flags & GEMM_KHI_N) khi = min(khi, n0 + BN);
+    klo = klo / BK * BK;
+    int nkt = khi > klo ? (khi - klo + BK - 1) / BK : 0;
+    int kt0 = 0, kt1 = nkt;
+    if (g.splitk > 1) {
+        const int per = (nkt + g.splitk - 1) / g.splitk;
+        kt0 = min(nkt, ks * per);
+        kt1 = min(nkt, kt0 + per);
+    }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave & 1) * (16 * TM), wn = (wave >> 1) * (16 * TN);
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    v4d acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    const bool tfA = g.fastA && (m0 + BM <= g.M);
+    const bool tfB = g.fastB && (n0 + BN <= g.N);
+    v2d ra[BM / 32], rb[BN / 32];
+    if (kt0 < kt1) {
+        const int k0 = klo + kt0 * BK;
+        const bool kin = k0 + BK <= g.K;
+        gload<BM, AKC>(g.A, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
+        gload<BN, BKC>(g.B, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
+    }
+    for (int kt = kt0; kt < kt1; ++kt) {
+        __syncthreads();
+        sstore<BM, AKC>(sA, ra);
+        sstore<BN, BKC>(sB, rb);
+        __syncthreads();
+        if (kt + 1 < kt1) {
+            const int k0 = klo + (kt + 1) * BK;
+            const bool kin = k0 + BK <= g.K;
+            gload<BM, AKC>(g.A, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
+            gload<BN, BKC>(g.B, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            double fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = sfrag<BM, AKC>(sA, wm + i * 16 + l15, kk * 4 + l4);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = sfrag<BN, BKC>(sB, wn + j * 16 + l15, kk * 4 + l4);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4) + 4r]
+    double* Cb = g.C + (g.splitk > 1 ? (long)ks * g.slab : 0);
+    const bool plain = g.splitk > 1 || g.beta == 0.0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm + i * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn + j * 16 + l4 + 4 * r;
+                if (m < g.M && n < g.N) {
+                    double* c = Cb + m + (long)n * g.ldc;
+                    const double v = g.alpha * acc[j][i][r];
+                    *c = plain ? v : v + g.beta * *c;
+                }
+            }
+        }
+}
+
+__global__ void splitk_reduce_kernel(double* __restrict__ C, long ldc, const double* __restrict__ W,
+                                     long slab, int splitk, int M, int N, double beta, int lower_bt) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)M * N) return;
+    const int m = (int)(idx % M), n = (int)(idx / M);
+    if (lower_bt && (n / lower_bt) > (m / lower_bt)) return;  // tiles above the diagonal were never written
+    double s = 0.0;
+    for (int k = 0; k < splitk; ++k) s += W[(long)k * slab + idx];
+    double* c = C + m + (long)n * ldc;
+    *c = beta == 0.0 ? s : s + beta * *c;
+}
+
+template <int TM, int TN>
+void launch(hipStream_t st, int a_kc, int b_kc, const GemmArgs& g, int grid) {
+    if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), dim3(grid), dim3(256), 0, st, g);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), dim3(grid), dim3(256), 0, st, g);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), dim3(grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), dim3(grid), dim3(256), 0, st, g);
+}
+
+int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
+              const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
+              int flags, int splitk, double* work) {
+    if (M <= 0 || N <= 0) return GPX_OK;
+    if (M > 0x7fffffffL - 256 || N > 0x7fffffffL - 256 || K > 0x7fffffffL - 256) return GPX_ERR_ARG;
+    if ((flags & GEMM_LOWER) && M != N) return GPX_ERR_ARG;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.alpha = alpha; g.beta = beta;
+    g.flags = flags;
+    g.fastA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 2 == 0);
+    g.fastB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 2 == 0);
+    // tile choice: 128x128 when that still fills the chip, 64x64 otherwise
+    int bt = 128;
+    {
+        const long t128 = ((M + 127) / 128) * ((N + 127) / 128) / ((flags & GEMM_LOWER) ? 2 : 1);
+        if (t128 * (splitk > 1 ? splitk : 1) < 384) bt = 64;
+    }
+    if (flags & GEMM_TILE64) bt = 64;
+    if (flags & GEMM_TILE128) bt = 128;
+    g.tiles_m = (int)((M + bt - 1) / bt);
+    g.tiles_n = (int)((N + bt - 1) / bt);
+    g.ntiles = (flags & GEMM_LOWER) ? g.tiles_m * (g.tiles_m + 1) / 2 : g.tiles_m * g.tiles_n;
+    g.splitk = splitk > 1 ? splitk : 1;
+    g.slab = M * N;
+    if (g.splitk > 1) {
+        g.C = work;
+        g.ldc = M;
+    }
+    const long grid = (long)g.ntiles * g.splitk;
+    if (grid > 0x7fffffffL) return GPX_ERR_ARG;
+    if (bt == 128) launch<4, 4>(st, a_kc, b_kc, g, (int)grid);
+    else launch<2, 2>(st, a_kc, b_kc, g, (int)grid);
+    if (g.splitk > 1) {
+        const long tot = M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C,
+                           ldc, work, g.slab, g.splitk, (int)M, (int)N, beta,
+                           (flags & GEMM_LOWER) ? bt : 0);
+    }
+    HIP_TRY(hipGetLastError());
+    return GPX_OK;
+}
+
+}  // namespace
+
+int gpx_gemm(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
+             const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
+             int flags) {
+    return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, 1, nullptr);
+}
+
+int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
+                    const double* A, long lda, const double* B, long ldb, double beta, double* C,
+                    long ldc, int flags, double* work, long work_doubles) {
+    int splitk = 1;
+    if (work) {
+        const long tiles = ((M + 63) / 64) * ((N + 63) / 64) / ((flags & GEMM_LOWER) ? 2 : 1);
+        const long kt = (K + BK - 1) / BK;
+        while (splitk < 64 && tiles * splitk < 1024 && kt / (splitk * 2) >= 16 &&
+               (long)(splitk * 2) * M * N <= work_doubles)
+            splitk *= 2;
+    }
+    return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, splitk, work);
+}

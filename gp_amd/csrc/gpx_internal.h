@@ -1,0 +1,59 @@
+// gpx_internal.h — shared declarations of the HIP side of libgpx.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+#define GPX_OK 0
+#define GPX_ERR_ARG 1
+#define GPX_ERR_HIP 2
+#define GPX_ERR_STATE 3
+#define GPX_ERR_UNSUPPORTED 4
+
+#define GPX_MAX_DIM 128   // input dimensions held in LDS by the pairwise kernels
+#define GPX_NB0 64        // base block of the recursive factorisations
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            fprintf(stderr, "gpx: HIP error %s at %s:%d: %s\n", hipGetErrorName(_e),         \
+                    __FILE__, __LINE__, #expr);                                             \
+            return GPX_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+// leading dimension for internal column-major matrices: multiple of 16 doubles (128 B), never a
+// multiple of 256 doubles so that column strides do not alias on HBM channels
+static inline long gpx_ld(long n) {
+    long ld = (n + 15) / 16 * 16;
+    if (ld % 256 == 0) ld += 16;
+    return ld;
+}
+
+// ---- GEMM (gemm_f64.hip) -------------------------------------------------------------------
+// C[M x N] = alpha * op(A) * op(B)^T + beta * C, all column-major.
+//   a_kc == 0: A(m,k) at A[m + k*lda] (M-contiguous);  a_kc == 1: A(m,k) at A[k + m*lda]
+//   b_kc == 0: B(n,k) at B[n + k*ldb] (N-contiguous);  b_kc == 1: B(n,k) at B[k + n*ldb]
+// flags:
+#define GEMM_LOWER 1        // M == N, only tiles on or below the diagonal are computed
+#define GEMM_KLO_M 2        // A(m,k) == 0 for k < m  -> tile skips k < m0
+#define GEMM_KLO_N 4        // B(n,k) == 0 for k < n
+#define GEMM_KHI_M 8        // A(m,k) == 0 for k > m  -> tile stops at k = m0 + BM
+#define GEMM_KHI_N 16       // B(n,k) == 0 for k > n
+#define GEMM_HEAVY_LAST 32  // tiles with large m0 carry the most work: launch them first
+#define GEMM_TILE64 64      // force 64x64 tiles
+#define GEMM_TILE128 128    // force 128x128 tiles
+int gpx_gemm(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
+             const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
+             int flags);
+// split-K variant for short-and-wide outputs (K >> M,N): partial slabs in `work`
+// (>= splitk*M*N doubles), then a deterministic reduction.  work may be NULL -> plain gemm.
+int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
+                    const double* A, long lda, const double* B, long ldb, double beta, double* C,
+                    long ldc, int flags, double* work, long work_doubles);

@@ -1,0 +1,72 @@
+"""GPU tests of the fp64 MFMA GEMM (gp_amd/csrc/gemm_f64.hip) through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from gp_amd import lib
+    return lib
+
+
+def test_mfma_layout_identity_asymmetric():
+    """A = I against an ASYMMETRIC B: a swapped C write or a wrong fragment map cannot hide."""
+    lib = _lib()
+    n = 64
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n) + 0.25  # B[j, k]
+    C = lib.dgemm(np.eye(n), B)       # C = I @ B.T
+    assert np.array_equal(C, B.T)
+    C = lib.dgemm(B, np.eye(n))       # C = B @ I
+    assert np.array_equal(C, B)
+
+
+@pytest.mark.parametrize("a_kc", [False, True])
+@pytest.mark.parametrize("b_kc", [False, True])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (257, 130, 77), (64, 300, 16), (500, 500, 123), (1024, 896, 512)])
+def test_gemm_layouts_and_ragged_shapes(a_kc, b_kc, shape):
+    lib = _lib()
+    M, N, K = shape
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.uniform(-1, 1, (M, K))
+    B = rng.uniform(-1, 1, (N, K))
+    C0 = rng.uniform(-1, 1, (M, N))
+    ref = 0.5 * A @ B.T - 2.0 * C0
+    for flags in (lib.GEMM_TILE64, lib.GEMM_TILE128):
+        C = lib.dgemm(A, B, C0, a_kc=a_kc, b_kc=b_kc, alpha=0.5, beta=-2.0, flags=flags)
+        assert np.max(np.abs(C - ref)) <= 1e-13 * K
+
+
+def test_gemm_lower_and_triangular_k_ranges():
+    lib = _lib()
+    n = 384
+    rng = np.random.default_rng(5)
+    L = np.tril(rng.uniform(-1, 1, (n, n)))
+    D = rng.uniform(-1, 1, (n, n))
+    for tile in (lib.GEMM_TILE64, lib.GEMM_TILE128):
+        # SYRK-like: lower tiles only
+        C = lib.dgemm(D, D, flags=lib.GEMM_LOWER | tile)
+        assert np.max(np.abs(np.tril(C) - np.tril(D @ D.T))) < 1e-11
+        # A lower triangular (k <= m): stop at the diagonal tile
+        C = lib.dgemm(L, D.T.copy(), flags=lib.GEMM_KHI_M | lib.GEMM_HEAVY_LAST | tile, b_kc=True)
+        assert np.max(np.abs(C - L @ D)) < 1e-11
+        # B(n,k) = W[k][n] with W lower triangular (nonzero k >= n): start at the diagonal tile
+        C = lib.dgemm(D, L.T.copy(), flags=lib.GEMM_KLO_N | tile, b_kc=True)
+        assert np.max(np.abs(C - D @ L)) < 1e-11
+        # W^T W, lower tiles, both operands K-contiguous with k >= max(m, n)
+        C = lib.dgemm(L.T.copy(), L.T.copy(), a_kc=True, b_kc=True, flags=lib.GEMM_LOWER | lib.GEMM_KLO_M | tile)
+        assert np.max(np.abs(np.tril(C) - np.tril(L.T @ L))) < 1e-11
+
+
+def test_gemm_splitk_tall():
+    lib = _lib()
+    M, N, K = 96, 160, 40000
+    rng = np.random.default_rng(9)
+    A = rng.uniform(-1, 1, (M, K))
+    B = rng.uniform(-1, 1, (N, K))
+    C0 = rng.uniform(-1, 1, (M, N))
+    C = lib.dgemm(A, B, C0, a_kc=True, b_kc=True, beta=1.0, splitk_work=64 * M * N)
+    assert np.max(np.abs(C - (A @ B.T + C0))) < 1e-10
+    D = rng.uniform(-1, 1, (M, K))
+    C = lib.dgemm(D, D, a_kc=True, b_kc=True, flags=lib.GEMM_LOWER, splitk_work=64 * M * M)
+    assert np.max(np.abs(np.tril(C) - np.tril(D @ D.T))) < 1e-10
