@@ -7,7 +7,7 @@ mkdir -p obj
 pids=()
 for f in *.hip; do
   o=obj/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ gpx_internal.h -nt "$o" ] || [ ../../include/gpx.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ gpx_internal.h -nt "$o" ] || [ kernels.h -nt "$o" ] || [ ctx.h -nt "$o" ] || [ ../../include/gpx.h -nt "$o" ]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -c "$f" -o "$o" &
     pids+=($!)
   fi

@@ -1,0 +1,196 @@
+// capi.hip — the high-level extern "C" entry points declared in include/gpx.h.
+#include "ctx.h"
+#include <cstring>
+#include <new>
+
+extern "C" {
+
+int gpx_ctx_create(int device, gpx_ctx** out) {
+    if (!out) return GPX_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return GPX_ERR_ARG;
+    HIP_TRY(hipSetDevice(device));
+    gpx_ctx* c = new (std::nothrow) gpx_ctx();
+    if (!c) return GPX_ERR_HIP;
+    c->dev = device;
+    HIP_TRY(hipStreamCreate(&c->st));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->info), 64));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->host_scal), 1024 * sizeof(double)));
+    int rc = c->scal.ensure(1024);
+    if (!rc) rc = c->trace_ws.ensure(GPX_TRACE_WS);
+    if (rc) return rc;
+    *out = c;
+    return GPX_OK;
+}
+
+int gpx_ctx_destroy(gpx_ctx* c) {
+    if (!c) return GPX_OK;
+    (void)hipSetDevice(c->dev);
+    (void)hipStreamSynchronize(c->st);
+    DevBuf* bufs[] = {&c->X, &c->y, &c->U, &c->Xt, &c->Ut, &c->A, &c->W, &c->T, &c->Wd, &c->r, &c->alpha,
+                      &c->nalpha, &c->scal, &c->trace_ws, &c->Kxu, &c->V, &c->Bm, &c->Cm, &c->Kuu, &c->Lu,
+                      &c->Am, &c->LA, &c->Winv_u, &c->Winv_A, &c->Kuu_inv, &c->A_inv, &c->Wuu, &c->Tm,
+                      &c->Wd_u, &c->Wd_A, &c->red, &c->pred_K, &c->pred_xs, &c->pred_xst, &c->pred_out,
+                      &c->pred_tmp};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& b : c->vn) b.release();
+    for (auto& b : c->vm) b.release();
+    if (c->info) (void)hipFree(c->info);
+    if (c->host_scal) (void)hipHostFree(c->host_scal);
+    (void)hipStreamDestroy(c->st);
+    delete c;
+    return GPX_OK;
+}
+
+int gpx_set_data(gpx_ctx* c, const double* X, const double* y, int64_t n, int64_t d) {
+    if (!c || !X || !y || n <= 0 || d <= 0) return GPX_ERR_ARG;
+    if (d > GPX_MAX_DIM) return GPX_ERR_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(c->dev));
+    c->prepared_model = -1;
+    c->n = n;
+    c->d = (int)d;
+    c->dpad = (int)((d + 7) / 8 * 8);
+    c->ldx = gpx_ld(n);
+    int rc;
+    if ((rc = c->X.ensure(n * d)) || (rc = c->y.ensure(n)) || (rc = c->Xt.ensure((long)c->dpad * c->ldx))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->X.p, X, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipMemcpyAsync(c->y.p, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    return GPX_OK;
+}
+
+int gpx_set_inducing(gpx_ctx* c, const double* U, int64_t m) {
+    if (!c || !U || m <= 0 || c->d <= 0) return GPX_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->dev));
+    c->prepared_model = -1;
+    c->m = m;
+    c->ldu = gpx_ld(m);
+    int rc;
+    if ((rc = c->U.ensure(m * c->d)) || (rc = c->Ut.ensure((long)c->dpad * c->ldu))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->U.p, U, (size_t)m * c->d * sizeof(double), hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    return GPX_OK;
+}
+
+int gpx_set_allreduce(gpx_ctx* c, gpx_allreduce_fn fn, void* user) {
+    if (!c) return GPX_ERR_ARG;
+    c->allreduce = fn;
+    c->allreduce_user = user;
+    return GPX_OK;
+}
+
+int gpx_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int calc_grad, double jitter, double* nll,
+                 double* grad) {
+    if (!c || !hyp || !nll || (calc_grad && !grad)) return GPX_ERR_ARG;
+    if (cov != GPX_COV_SE_ARD && cov != GPX_COV_SE_ISO) return GPX_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->dev));
+    if (model == GPX_MODEL_EXACT) return gpx_exact_nll_grad(c, cov, hyp, calc_grad, nll, grad);
+    if (model == GPX_MODEL_FITC || model == GPX_MODEL_VFE)
+        return gpx_sparse_nll_grad(c, model, cov, hyp, calc_grad, jitter, nll, grad);
+    return GPX_ERR_ARG;
+}
+
+int gpx_prepare(gpx_ctx* c, int model, int cov, double* hyp, double* jitter) {
+    if (!c || !hyp) return GPX_ERR_ARG;
+    if (cov != GPX_COV_SE_ARD && cov != GPX_COV_SE_ISO) return GPX_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->dev));
+    if (model == GPX_MODEL_EXACT) return gpx_exact_prepare(c, cov, hyp);
+    if ((model == GPX_MODEL_FITC || model == GPX_MODEL_VFE) && jitter)
+        return gpx_sparse_prepare(c, model, cov, hyp, jitter);
+    return GPX_ERR_ARG;
+}
+
+int gpx_predict(gpx_ctx* c, const double* Xs, int64_t t, double* mu, double* s2) {
+    if (!c || !Xs || t < 0) return GPX_ERR_ARG;
+    if (t == 0) return GPX_OK;
+    HIP_TRY(hipSetDevice(c->dev));
+    if (c->prepared_model == GPX_MODEL_EXACT) return gpx_exact_predict(c, Xs, t, mu, s2);
+    if (c->prepared_model == GPX_MODEL_FITC || c->prepared_model == GPX_MODEL_VFE)
+        return gpx_sparse_predict(c, Xs, t, mu, s2);
+    return GPX_ERR_STATE;
+}
+
+int gpx_cov_k(int cov, int64_t d, const double* hyp, const double* x1, int64_t p, const double* x2, int64_t q,
+              double* K) {
+    if (!hyp || !x1 || !x2 || !K || p <= 0 || q <= 0 || d <= 0) return GPX_ERR_ARG;
+    if (d > GPX_MAX_DIM) return GPX_ERR_UNSUPPORTED;
+    const int nk = cov == GPX_COV_SE_ARD ? (int)d + 1 : 2;
+    std::vector<double> h(hyp, hyp + nk);
+    h.push_back(0.0);
+    h.push_back(0.0);
+    HypView hv;
+    int rc = parse_hyp(cov, (int)d, h.data(), hv);
+    if (rc) return rc;
+    const int dpad = (int)((d + 7) / 8 * 8);
+    const long l1 = gpx_ld(p), l2 = gpx_ld(q);
+    DevBuf X1, X2, T1, T2, Kd;
+    rc = X1.ensure(p * d);
+    if (!rc) rc = X2.ensure(q * d);
+    if (!rc) rc = T1.ensure(dpad * l1);
+    if (!rc) rc = T2.ensure(dpad * l2);
+    if (!rc) rc = Kd.ensure(p * q);
+    if (!rc) {
+        rc = GPX_ERR_HIP;
+        if (hipMemcpy(X1.p, x1, (size_t)p * d * 8, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(X2.p, x2, (size_t)q * d * 8, hipMemcpyHostToDevice) == hipSuccess) {
+            rc = gpx_scale_inputs(0, X1.p, p, (int)d, dpad, hv.sc, T1.p, l1);
+            if (!rc) rc = gpx_scale_inputs(0, X2.p, q, (int)d, dpad, hv.sc, T2.p, l2);
+            if (!rc) rc = gpx_cov_build(0, T1.p, l1, p, T2.p, l2, q, dpad, hv.sf2, Kd.p, p, 0, 0.0);
+            if (!rc && hipMemcpy(K, Kd.p, (size_t)p * q * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = GPX_ERR_HIP;
+        }
+    }
+    X1.release(); X2.release(); T1.release(); T2.release(); Kd.release();
+    return rc;
+}
+
+int gpx_chol_solve(int64_t n, const double* A, int* spd, double* logdet, double* B, int64_t nrhs, double* Inv) {
+    if (!A || !spd || n <= 0 || nrhs < 0 || (nrhs > 0 && !B)) return GPX_ERR_ARG;
+    const long ld = gpx_ld(n);
+    DevBuf L, Wd, W, T, Bd, sc;
+    int* info = nullptr;
+    int rc = L.ensure(ld * n);
+    if (!rc) rc = Wd.ensure(64L * ((n + 63) / 64 * 64));
+    if (!rc) rc = sc.ensure(8);
+    if (!rc && hipMalloc(reinterpret_cast<void**>(&info), 64) != hipSuccess) rc = GPX_ERR_HIP;
+    auto done = [&](int r) {
+        L.release(); Wd.release(); W.release(); T.release(); Bd.release(); sc.release();
+        if (info) (void)hipFree(info);
+        return r;
+    };
+    if (rc) return done(rc);
+    if (hipMemcpy2D(L.p, ld * 8, A, n * 8, n * 8, n, hipMemcpyHostToDevice) != hipSuccess) return done(GPX_ERR_HIP);
+    if (hipMemset(info, 0, 4) != hipSuccess) return done(GPX_ERR_HIP);
+    if ((rc = gpx_potrf(0, n, L.p, ld, Wd.p, info))) return done(rc);
+    int hinfo = 0;
+    if (hipMemcpy(&hinfo, info, 4, hipMemcpyDeviceToHost) != hipSuccess) return done(GPX_ERR_HIP);
+    *spd = hinfo == 0;
+    if (!*spd) return done(GPX_OK);
+    if (logdet) {
+        if ((rc = gpx_logdiag_sum(0, n, L.p, ld, sc.p))) return done(rc);
+        double s;
+        if (hipMemcpy(&s, sc.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return done(GPX_ERR_HIP);
+        *logdet = 2 * s;
+    }
+    if (nrhs > 0) {
+        if ((rc = Bd.ensure(ld * nrhs))) return done(rc);
+        if (hipMemcpy2D(Bd.p, ld * 8, B, n * 8, n * 8, nrhs, hipMemcpyHostToDevice) != hipSuccess) return done(GPX_ERR_HIP);
+        if ((rc = gpx_trsm_left(0, n, nrhs, L.p, ld, Wd.p, Bd.p, ld, 0))) return done(rc);
+        if ((rc = gpx_trsm_left(0, n, nrhs, L.p, ld, Wd.p, Bd.p, ld, 1))) return done(rc);
+        if (hipMemcpy2D(B, n * 8, Bd.p, ld * 8, n * 8, nrhs, hipMemcpyDeviceToHost) != hipSuccess) return done(GPX_ERR_HIP);
+    }
+    if (Inv) {
+        if ((rc = W.ensure(ld * n)) || (rc = T.ensure(gpx_trtri_scratch(n)))) return done(rc);
+        if (hipMemset(W.p, 0, (size_t)ld * n * 8) != hipSuccess) return done(GPX_ERR_HIP);
+        if ((rc = gpx_trtri(0, n, L.p, ld, Wd.p, W.p, ld, T.p))) return done(rc);
+        if ((rc = gpx_lauum(0, n, W.p, ld, L.p, ld))) return done(rc);
+        if (hipMemcpy2D(Inv, n * 8, L.p, ld * 8, n * 8, n, hipMemcpyDeviceToHost) != hipSuccess) return done(GPX_ERR_HIP);
+        // mirror the lower triangle (the device keeps only the lower tiles)
+        for (int64_t j = 0; j < n; ++j)
+            for (int64_t i = j + 1; i < n; ++i) Inv[j + i * n] = Inv[i + j * n];
+    }
+    return done(GPX_OK);
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// ctx.h — the opaque context behind the C ABI: device-resident training data and workspaces.
+#pragma once
+#include "gpx_internal.h"
+#include "kernels.h"
+#include "../../include/gpx.h"
+#include <vector>
+
+struct DevBuf {
+    double* p = nullptr;
+    long cap = 0;  // doubles
+    int ensure(long count) {
+        if (count <= cap) return GPX_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p), (size_t)count * sizeof(double)));
+        cap = count;
+        return GPX_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct gpx_ctx {
+    int dev = 0;
+    hipStream_t st = nullptr;
+    // training data (device): X is d x n as given, y length n
+    long n = 0, m = 0;
+    int d = 0, dpad = 0;
+    DevBuf X, y, U;
+    DevBuf Xt, Ut;  // scaled, dimension-major [dpad][ld]
+    long ldx = 0, ldu = 0;
+    // dense workspaces
+    DevBuf A, W, T, Wd;  // exact: n x n factor / inverse, trtri scratch, base-block inverses
+    long lda = 0;
+    DevBuf r, alpha, nalpha;
+    DevBuf scal;      // small device result vector
+    DevBuf trace_ws;  // pair_trace partials
+    int* info = nullptr;
+    double* host_scal = nullptr;  // pinned
+    // sparse workspaces (sparse.hip)
+    DevBuf Kxu, V, Bm, Cm, Kuu, Lu, Am, LA, Winv_u, Winv_A, Kuu_inv, A_inv, Wuu, Tm, Wd_u, Wd_A;
+    DevBuf vn[8], vm[8], red;
+    // all-reduce hook for row-sharded FITC/VFE
+    gpx_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+    // state left by gpx_prepare for gpx_predict
+    int prepared_model = -1, prepared_cov = 0;
+    std::vector<double> prepared_hyp;
+    double prepared_jitter = 0;
+    DevBuf pred_K, pred_xs, pred_xst, pred_out, pred_tmp;
+};
+
+struct HypView {
+    int nk;            // kernel hypers: d+1 (ARD) or 2 (iso)
+    double sf2, sn2, mean;
+    ScaleArgs sc;
+};
+inline int parse_hyp(int cov, int d, const double* hyp, HypView& h) {
+    if (d > GPX_MAX_DIM) return GPX_ERR_UNSUPPORTED;
+    h.nk = cov == GPX_COV_SE_ARD ? d + 1 : 2;
+    h.sf2 = exp(2 * hyp[h.nk - 1]);
+    h.sn2 = exp(2 * hyp[h.nk]);
+    h.mean = hyp[h.nk + 1];
+    if (cov == GPX_COV_SE_ARD) {
+        h.sc.divide = 0;
+        for (int i = 0; i < d; ++i) h.sc.s[i] = exp(-1 * hyp[i]);  // CovSEard.cpp:9
+    } else {
+        h.sc.divide = 1;
+        const double l = exp(hyp[0]);  // CovSEiso.cpp:8
+        for (int i = 0; i < d; ++i) h.sc.s[i] = l;
+    }
+    return GPX_OK;
+}
+
+// exact.hip
+int gpx_exact_nll_grad(gpx_ctx* c, int cov, const double* hyp, int calc_grad, double* nll, double* grad);
+int gpx_exact_prepare(gpx_ctx* c, int cov, double* hyp);
+int gpx_exact_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double* s2);
+// sparse.hip
+int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int calc_grad, double jitter,
+                        double* nll, double* grad);
+int gpx_sparse_prepare(gpx_ctx* c, int model, int cov, const double* hyp, double* jitter);
+int gpx_sparse_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double* s2);
+// small shared kernels (exact.hip)
+int gpx_vec_shift(hipStream_t st, long n, const double* y, double shift, double scale, double* out);
+int gpx_reduce3(hipStream_t st, long n, const double* a, const double* b, double* out3);
+int gpx_colsumsq(hipStream_t st, long n, long t, const double* V, long ldv, double* out);

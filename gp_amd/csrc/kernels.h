@@ -1,0 +1,54 @@
+// kernels.h — internal interfaces between the HIP translation units of libgpx.so.
+#pragma once
+#include "gpx_internal.h"
+
+// ---- pairwise.hip ---------------------------------------------------------------------------
+struct ScaleArgs {
+    double s[GPX_MAX_DIM];  // per-dimension factor
+    int divide;             // 0: x * s_i (SE-ARD, s_i = exp(-hyp_i)); 1: x / s_i (SE-iso, s = exp(hyp_0))
+};
+struct TraceArgs {
+    const double* Xt1; long ld1; long p;   // scaled inputs, dimension-major [dpad][ld]
+    const double* Xt2; long ld2; long q;
+    int dpad, dim0;
+    double sf2;
+    const double* M1; long ldm1; const double* c1;  // w_ab  = c1_a * M1_ab   (c1 NULL -> 1)
+    const double* M2; long ldm2; const double* c2;  //       + c2_a * M2_ab   (M2 NULL -> absent)
+    const double* u; const double* v;               //       + u_a * v_b      (u NULL -> absent)
+    int sym;          // p == q, M1 symmetric and valid in its lower triangle: visit tiles a >= b only
+    double* partial;  // filled in by gpx_pair_trace
+    int ntiles, tiles_p;
+};
+int gpx_scale_inputs(hipStream_t st, const double* X, long n, int d, int dpad, const ScaleArgs& sc,
+                     double* Xt, long ldx);
+int gpx_cov_build(hipStream_t st, const double* Xt1, long ld1, long p, const double* Xt2, long ld2, long q,
+                  int dpad, double sf2, double* out, long ldo, int lower, double diag_add);
+// out[0..d-1] = S_i, out[d] = sum w K, out[d+1] = tr(w); partial_ws >= 2048*34 doubles
+int gpx_pair_trace(hipStream_t st, TraceArgs g, int d, double* partial_ws, long ws_doubles, double* out);
+#define GPX_TRACE_WS (2048L * 34)
+
+// ---- chol.hip -------------------------------------------------------------------------------
+// Blocked recursive lower Cholesky in place (lower triangle of A).  Wd (64 x roundup(n,64),
+// ld 64) receives the inverse of every 64x64 diagonal base block; *info (device int, must be 0
+// on entry) is set to 1 when a pivot is not positive.
+int gpx_potrf(hipStream_t st, long n, double* A, long lda, double* Wd, int* info);
+// W = L^-1 (lower, n x n, ld ldw; W must be zero above the diagonal on entry), T scratch of
+// gpx_trtri_scratch(n) doubles.
+long gpx_trtri_scratch(long n);
+int gpx_trtri(hipStream_t st, long n, const double* L, long ldl, const double* Wd, double* W, long ldw,
+              double* T);
+// Out (lower tiles) = W^T W
+int gpx_lauum(hipStream_t st, long n, const double* W, long ldw, double* Out, long ldo);
+// b <- L^-1 b (trans = 0) or L^-T b (trans = 1); b has nrhs columns of leading dimension ldb
+int gpx_trsv(hipStream_t st, long n, const double* L, long ldl, const double* Wd, double* b, int trans);
+int gpx_trsm_left(hipStream_t st, long n, long nrhs, const double* L, long ldl, const double* Wd, double* B,
+                  long ldb, int trans);
+// out[0] = sum_i log A[i + i*lda]
+int gpx_logdiag_sum(hipStream_t st, long n, const double* A, long lda, double* out);
+
+// ---- vecops.hip -----------------------------------------------------------------------------
+// y -= A x (A M x K, M-contiguous) ; y -= A^T x (y has K entries)
+int gpx_gemv_n(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
+               double beta, double* y);
+int gpx_gemv_t(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
+               double beta, double* y);

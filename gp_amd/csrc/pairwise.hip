@@ -1,0 +1,270 @@
+// pairwise.hip — squared-exponential kernel matrices and fused weighted-derivative sums (gfx950).
+//
+//  * scale_inputs : Xt[i][a] = x_ia / l_i, stored dimension-major so that a 64-point tile of one
+//                   dimension is one 512-B coalesced read (CovSEard.cpp:9, CovSEiso.cpp:8-10).
+//  * cov_build    : K_ab = sf2 * exp(-r2_ab / 2) from direct differences of the scaled inputs
+//                   (util.cpp:64-75 is direct-difference too, so the diagonal of k(X,X) is exactly
+//                   sf2), optional lower-triangle-only output and a diagonal shift (sn2 / jitter).
+//  * pair_trace   : for a weight matrix w_ab given as c1_a*M1_ab + c2_a*M2_ab + u_a*v_b, the sums
+//                   S_i = sum_ab w_ab K_ab ((x_ia - x_ib)/l_i)^2 for every dimension i, S_K = sum w K
+//                   and tr(w): every dK/dtheta of CovSEard.cpp:12-22 contracted with the weights
+//                   in ONE pass, K recomputed on the fly, dK never materialised (replaces the
+//                   per-hyper loops GP.cpp:155-161, FITC.cpp:269-308, VFE.cpp:213-237).
+// All three are HBM/VALU-bound O(p q d) kernels: 64x64 tiles, 256 threads, lanes along the
+// first index so every global access is a contiguous 512-B row per wave.
+#include "gpx_internal.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int DCH = 32;  // dimensions staged in LDS at a time
+
+__global__ void scale_inputs_kernel(const double* __restrict__ X, long n, int d, int dpad,
+                                    ScaleArgs sc, double* __restrict__ Xt, long ldx) {
+    const long a = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    for (int i = 0; i < dpad; ++i) {
+        double v = 0.0;
+        if (i < d) {
+            const double x = X[i + a * (long)d];
+            v = sc.divide ? x / sc.s[i] : x * sc.s[i];
+        }
+        Xt[(long)i * ldx + a] = v;
+    }
+}
+
+__device__ __forceinline__ void decode_tile(int tile, bool lower, int tiles_p, int& ta, int& tb) {
+    if (lower) {
+        ta = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+        while (ta * (ta + 1) / 2 > tile) --ta;
+        while ((ta + 1) * (ta + 2) / 2 <= tile) ++ta;
+        tb = tile - ta * (ta + 1) / 2;
+    } else {
+        ta = tile % tiles_p;
+        tb = tile / tiles_p;
+    }
+}
+
+// stage dims [c0, c0+cw) of a 64-point tile of each input set into LDS
+__device__ __forceinline__ void stage(double (*sa)[64], double (*sb)[64], const double* __restrict__ Xt1,
+                                      long ld1, long p, long a0, const double* __restrict__ Xt2, long ld2,
+                                      long q, long b0, int c0, int cw, int dpad) {
+    for (int idx = threadIdx.x; idx < cw * 64; idx += 256) {
+        const int i = idx >> 6, l = idx & 63;
+        const bool din = c0 + i < dpad;
+        sa[i][l] = (din && a0 + l < p) ? Xt1[(long)(c0 + i) * ld1 + a0 + l] : 0.0;
+        sb[i][l] = (din && b0 + l < q) ? Xt2[(long)(c0 + i) * ld2 + b0 + l] : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void cov_build_kernel(const double* __restrict__ Xt1, long ld1, long p,
+                                                        const double* __restrict__ Xt2, long ld2, long q,
+                                                        int dpad, double sf2, double* __restrict__ out,
+                                                        long ldo, int lower, int tiles_p, double diag_add) {
+    __shared__ double sa[DCH][64], sb[DCH][64];
+    int ta, tb;
+    decode_tile(blockIdx.x, lower, tiles_p, ta, tb);
+    const long a0 = (long)ta * 64, b0 = (long)tb * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    double r2[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r2[k] = 0.0;
+    for (int c0 = 0; c0 < dpad; c0 += DCH) {
+        const int cw = min(DCH, dpad - c0);
+        __syncthreads();
+        stage(sa, sb, Xt1, ld1, p, a0, Xt2, ld2, q, b0, c0, cw, dpad);
+        __syncthreads();
+        for (int i = 0; i < cw; ++i) {
+            const double xa = sa[i][tx];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const double t = xa - sb[i][ty * 16 + k];
+                r2[k] = fma(t, t, r2[k]);
+            }
+        }
+    }
+    const long a = a0 + tx;
+    if (a < p) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const long b = b0 + ty * 16 + k;
+            if (b < q) {
+                double v = sf2 * exp(-0.5 * r2[k]);
+                if (a == b) v += diag_add;
+                out[a + b * ldo] = v;
+            }
+        }
+    }
+}
+
+template <int DC>
+__global__ __launch_bounds__(256) void pair_trace_kernel(const TraceArgs g) {
+    __shared__ double sa[DCH][64], sb[DCH][64];
+    __shared__ double red[4][DC + 2];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    double acc[DC];
+#pragma unroll
+    for (int i = 0; i < DC; ++i) acc[i] = 0.0;
+    double sK = 0.0, tr = 0.0;
+    const bool single = g.dpad <= DCH;  // the whole input fits one staging pass
+
+    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+        int ta, tb;
+        decode_tile(tile, g.sym != 0, g.tiles_p, ta, tb);
+        const long a0 = (long)ta * 64, b0 = (long)tb * 64;
+        double r2[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r2[k] = 0.0;
+        for (int c0 = 0; c0 < g.dpad; c0 += DCH) {
+            const int cw = min(DCH, g.dpad - c0);
+            __syncthreads();
+            stage(sa, sb, g.Xt1, g.ld1, g.p, a0, g.Xt2, g.ld2, g.q, b0, c0, cw, g.dpad);
+            __syncthreads();
+            for (int i = 0; i < cw; ++i) {
+                const double xa = sa[i][tx];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const double t = xa - sb[i][ty * 16 + k];
+                    r2[k] = fma(t, t, r2[k]);
+                }
+            }
+        }
+        // weights times K
+        const long a = a0 + tx;
+        const bool ain = a < g.p;
+        const double c1a = (ain && g.c1) ? g.c1[a] : 1.0;
+        const double c2a = (ain && g.c2) ? g.c2[a] : 1.0;
+        const double ua = (ain && g.u) ? g.u[a] : 0.0;
+        const double symw = (g.sym && ta != tb) ? 2.0 : 1.0;
+        double qk[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const long b = b0 + ty * 16 + k;
+            double w = 0.0;
+            if (ain && b < g.q) {
+                // in symmetric mode only the lower triangle of M1 is valid
+                const long ia = (g.sym && a < b) ? b : a, ib = (g.sym && a < b) ? a : b;
+                w = c1a * g.M1[ia + ib * g.ldm1];
+                if (g.M2) w += c2a * g.M2[a + b * g.ldm2];
+                if (g.u) w += ua * g.v[b];
+                if (a == b) tr += w;
+            }
+            qk[k] = symw * w * (g.sf2 * exp(-0.5 * r2[k]));
+            sK += qk[k];
+        }
+        // per-dimension sums for dims [dim0, dim0+DC)
+        if (!single) {
+            __syncthreads();
+            stage(sa, sb, g.Xt1, g.ld1, g.p, a0, g.Xt2, g.ld2, g.q, b0, g.dim0, DC, g.dpad);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < DC; ++i) {
+            const double xa = sa[i][tx];
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const double t = xa - sb[i][ty * 16 + k];
+                s = fma(qk[k], t * t, s);
+            }
+            acc[i] += s;
+        }
+    }
+    // block reduction -> one partial row per workgroup
+    auto wave_sum = [](double v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+#pragma unroll
+    for (int i = 0; i < DC; ++i) {
+        const double s = wave_sum(acc[i]);
+        if (tx == 0) red[ty][i] = s;
+    }
+    {
+        const double s1 = wave_sum(sK), s2 = wave_sum(tr);
+        if (tx == 0) {
+            red[ty][DC] = s1;
+            red[ty][DC + 1] = s2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < DC + 2) {
+        const int i = threadIdx.x;
+        g.partial[(long)blockIdx.x * (DC + 2) + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+}
+
+// out[off_i] = sum over workgroups of partial[wg][i]
+__global__ void trace_finish_kernel(const double* __restrict__ partial, int nwg, int width, int dim0,
+                                    int ndims, int d, int write_tail, double* __restrict__ out) {
+    const int i = blockIdx.x;  // column of the partial table
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int w = threadIdx.x; w < nwg; w += 256) s += partial[(long)w * width + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (i < ndims) {
+            if (dim0 + i < d) out[dim0 + i] = red[0];
+        } else if (write_tail) {
+            out[d + (i - ndims)] = red[0];  // out[d] = sum w K, out[d+1] = tr(w)
+        }
+    }
+}
+
+}  // namespace
+
+int gpx_scale_inputs(hipStream_t st, const double* X, long n, int d, int dpad, const ScaleArgs& sc,
+                     double* Xt, long ldx) {
+    if (n <= 0) return GPX_OK;
+    hipLaunchKernelGGL(scale_inputs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, n, d, dpad,
+                       sc, Xt, ldx);
+    HIP_TRY(hipGetLastError());
+    return GPX_OK;
+}
+
+int gpx_cov_build(hipStream_t st, const double* Xt1, long ld1, long p, const double* Xt2, long ld2, long q,
+                  int dpad, double sf2, double* out, long ldo, int lower, double diag_add) {
+    if (p <= 0 || q <= 0) return GPX_OK;
+    if (lower && p != q) return GPX_ERR_ARG;
+    const long tp = (p + 63) / 64, tq = (q + 63) / 64;
+    const long ntiles = lower ? tp * (tp + 1) / 2 : tp * tq;
+    if (ntiles > 0x7fffffffL) return GPX_ERR_ARG;
+    hipLaunchKernelGGL(cov_build_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, Xt1, ld1, p, Xt2, ld2, q,
+                       dpad, sf2, out, ldo, lower, (int)tp, diag_add);
+    HIP_TRY(hipGetLastError());
+    return GPX_OK;
+}
+
+int gpx_pair_trace(hipStream_t st, TraceArgs g, int d, double* partial_ws, long ws_doubles, double* out) {
+    if (g.p <= 0 || g.q <= 0) return GPX_ERR_ARG;
+    if (g.sym && g.p != g.q) return GPX_ERR_ARG;
+    const long tp = (g.p + 63) / 64, tq = (g.q + 63) / 64;
+    const long ntiles = g.sym ? tp * (tp + 1) / 2 : tp * tq;
+    if (ntiles > 0x7fffffffL) return GPX_ERR_ARG;
+    g.ntiles = (int)ntiles;
+    g.tiles_p = (int)tp;
+    g.partial = partial_ws;
+    const int dc = g.dpad <= 8 ? 8 : g.dpad <= 16 ? 16 : g.dpad <= 24 ? 24 : 32;
+    const int width = dc + 2;
+    long nwg = ntiles < 2048 ? ntiles : 2048;
+    if (nwg * width > ws_doubles) nwg = ws_doubles / width;
+    if (nwg <= 0) return GPX_ERR_ARG;
+    for (int dim0 = 0; dim0 < g.dpad; dim0 += dc) {
+        g.dim0 = dim0;
+        switch (dc) {
+            case 8: hipLaunchKernelGGL(pair_trace_kernel<8>, dim3((unsigned)nwg), dim3(256), 0, st, g); break;
+            case 16: hipLaunchKernelGGL(pair_trace_kernel<16>, dim3((unsigned)nwg), dim3(256), 0, st, g); break;
+            case 24: hipLaunchKernelGGL(pair_trace_kernel<24>, dim3((unsigned)nwg), dim3(256), 0, st, g); break;
+            default: hipLaunchKernelGGL(pair_trace_kernel<32>, dim3((unsigned)nwg), dim3(256), 0, st, g); break;
+        }
+        hipLaunchKernelGGL(trace_finish_kernel, dim3(width), dim3(256), 0, st, partial_ws, (int)nwg, width, dim0,
+                           dc, d, dim0 == 0 ? 1 : 0, out);
+    }
+    HIP_TRY(hipGetLastError());
+    return GPX_OK;
+}

@@ -1,0 +1,70 @@
+// vecops.hip — memory-bound vector / matrix-vector helpers (gfx950).
+#include "gpx_internal.h"
+#include "kernels.h"
+
+namespace {
+
+// y[i] = beta*y[i] + alpha * sum_k A[i + k*lda] x[k]; 64 rows per workgroup, 4 waves split K
+__global__ __launch_bounds__(256) void gemv_n_kernel(long M, long K, double alpha, const double* __restrict__ A,
+                                                     long lda, const double* __restrict__ x, double beta,
+                                                     double* __restrict__ y) {
+    __shared__ double red[4][64];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + l;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (i < M) {
+        const double* a = A + i;
+        long k = w;
+        for (; k + 12 < K; k += 16) {
+            s0 = fma(a[k * lda], x[k], s0);
+            s1 = fma(a[(k + 4) * lda], x[k + 4], s1);
+            s2 = fma(a[(k + 8) * lda], x[k + 8], s2);
+            s3 = fma(a[(k + 12) * lda], x[k + 12], s3);
+        }
+        for (; k < K; k += 4) s0 = fma(a[k * lda], x[k], s0);
+    }
+    red[w][l] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && i < M) {
+        const double t = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        y[i] = beta == 0.0 ? alpha * t : beta * y[i] + alpha * t;
+    }
+}
+
+// y[j] = beta*y[j] + alpha * sum_i A[i + j*lda] x[i]; one wave per column
+__global__ __launch_bounds__(256) void gemv_t_kernel(long M, long K, double alpha, const double* __restrict__ A,
+                                                     long lda, const double* __restrict__ x, double beta,
+                                                     double* __restrict__ y) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * 4 + w;
+    if (j >= K) return;
+    const double* a = A + j * lda;
+    double s0 = 0.0, s1 = 0.0;
+    long i = l;
+    for (; i + 64 < M; i += 128) {
+        s0 = fma(a[i], x[i], s0);
+        s1 = fma(a[i + 64], x[i + 64], s1);
+    }
+    for (; i < M; i += 64) s0 = fma(a[i], x[i], s0);
+    double s = s0 + s1;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (l == 0) y[j] = beta == 0.0 ? alpha * s : beta * y[j] + alpha * s;
+}
+
+}  // namespace
+
+int gpx_gemv_n(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
+               double beta, double* y) {
+    if (M <= 0) return GPX_OK;
+    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, st, M, K, alpha, A, lda, x,
+                       beta, y);
+    return GPX_OK;
+}
+
+int gpx_gemv_t(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
+               double beta, double* y) {
+    if (K <= 0) return GPX_OK;
+    hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, st, M, K, alpha, A, lda, x, beta,
+                       y);
+    return GPX_OK;
+}

@@ -111,3 +111,126 @@ def dgemm(A, B, C_in=None, a_kc=False, b_kc=False, alpha=1.0, beta=0.0, flags=0,
         check(lib.gpx_dgemm(int(a_kc), int(b_kc), M, N, K, alpha, dA.ptr, lda, dB.ptr, ldb, beta, dC.ptr, M,
                             flags), "dgemm")
     return dC.to_numpy().reshape(N, M).T.copy()
+
+
+# ---- high-level API ---------------------------------------------------------------------------
+MODEL_EXACT, MODEL_FITC, MODEL_VFE = 0, 1, 2
+COV_SE_ARD, COV_SE_ISO = 0, 1
+ALLREDUCE_FN = C.CFUNCTYPE(_i, _vp, _i64, _vp)
+
+lib.gpx_ctx_create.argtypes = [_i, C.POINTER(_vp)]
+lib.gpx_ctx_destroy.argtypes = [_vp]
+lib.gpx_set_data.argtypes = [_vp, _vp, _vp, _i64, _i64]
+lib.gpx_set_inducing.argtypes = [_vp, _vp, _i64]
+lib.gpx_set_allreduce.argtypes = [_vp, ALLREDUCE_FN, _vp]
+lib.gpx_nll_grad.argtypes = [_vp, _i, _i, _vp, _i, _d, C.POINTER(_d), _vp]
+lib.gpx_prepare.argtypes = [_vp, _i, _i, _vp, C.POINTER(_d)]
+lib.gpx_predict.argtypes = [_vp, _vp, _i64, _vp, _vp]
+lib.gpx_cov_k.argtypes = [_i, _i64, _vp, _vp, _i64, _vp, _i64, _vp]
+lib.gpx_chol_solve.argtypes = [_i64, _vp, C.POINTER(_i), C.POINTER(_d), _vp, _i64, _vp]
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def num_hyp(cov, d):
+    return (d + 1 if cov == COV_SE_ARD else 2) + 2
+
+
+class Context:
+    """One GPU context = one GP object's device state.  X is (n, d) with one point per row
+    (C order), which is the reference's d x n column-major layout byte for byte."""
+
+    def __init__(self, device=0):
+        h = _vp()
+        check(lib.gpx_ctx_create(device, C.byref(h)), "ctx_create")
+        self._h = h
+        self.d = 0
+        self._cb = None
+
+    def set_data(self, X, y):
+        X, y = _c(X), _c(y)
+        n, self.d = X.shape
+        assert y.shape == (n,)
+        check(lib.gpx_set_data(self._h, X.ctypes.data, y.ctypes.data, n, self.d), "set_data")
+
+    def set_inducing(self, U):
+        U = _c(U)
+        assert U.shape[1] == self.d
+        check(lib.gpx_set_inducing(self._h, U.ctypes.data, U.shape[0]), "set_inducing")
+
+    def set_allreduce(self, fn):
+        """fn(device_ptr:int, count:int) -> None: in-place sum all-reduce of `count` doubles."""
+        def tramp(buf, count, user):
+            try:
+                fn(buf, count)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print("gpx allreduce callback failed:", e)
+                return 1
+        self._cb = ALLREDUCE_FN(tramp)
+        check(lib.gpx_set_allreduce(self._h, self._cb, None), "set_allreduce")
+
+    def nll_grad(self, model, cov, hyp, calc_grad=True, jitter=0.0):
+        hyp = _c(hyp)
+        assert hyp.shape == (num_hyp(cov, self.d),)
+        nll = _d(0.0)
+        g = np.zeros_like(hyp)
+        check(lib.gpx_nll_grad(self._h, model, cov, hyp.ctypes.data, int(calc_grad), jitter, C.byref(nll),
+                               g.ctypes.data if calc_grad else None), "nll_grad")
+        return (nll.value, g) if calc_grad else nll.value
+
+    def prepare(self, model, cov, hyp, jitter=0.0):
+        hyp = _c(hyp).copy()
+        j = _d(jitter)
+        check(lib.gpx_prepare(self._h, model, cov, hyp.ctypes.data, C.byref(j)), "prepare")
+        return hyp, j.value
+
+    def predict(self, Xs, want_mu=True, want_s2=True):
+        Xs = _c(Xs)
+        t = Xs.shape[0]
+        mu = np.empty(t) if want_mu else None
+        s2 = np.empty(t) if want_s2 else None
+        check(lib.gpx_predict(self._h, Xs.ctypes.data, t, mu.ctypes.data if want_mu else None,
+                              s2.ctypes.data if want_s2 else None), "predict")
+        return mu, s2
+
+    def close(self):
+        if self._h:
+            lib.gpx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cov_k(cov, hyp, x1, x2):
+    x1, x2, hyp = _c(x1), _c(x2), _c(hyp)
+    p, d = x1.shape
+    q = x2.shape[0]
+    K = np.empty((q, p))
+    check(lib.gpx_cov_k(cov, d, hyp.ctypes.data, x1.ctypes.data, p, x2.ctypes.data, q, K.ctypes.data), "cov_k")
+    return K.T
+
+
+def chol_solve(A, B=None, want_inverse=False):
+    """Returns (spd, logdet, X, Inv) for symmetric A (lower triangle read)."""
+    A = np.asarray(A, dtype=np.float64)
+    n = A.shape[0]
+    Ac = colmajor(A)
+    spd, ld = _i(0), _d(0.0)
+    Bc = None
+    nrhs = 0
+    if B is not None:
+        B = np.asarray(B, dtype=np.float64).reshape(n, -1)
+        nrhs = B.shape[1]
+        Bc = colmajor(B).copy()
+    Inv = np.empty(n * n) if want_inverse else None
+    check(lib.gpx_chol_solve(n, Ac.ctypes.data, C.byref(spd), C.byref(ld), Bc.ctypes.data if nrhs else None, nrhs,
+                             Inv.ctypes.data if want_inverse else None), "chol_solve")
+    X = Bc.reshape(nrhs, n).T.copy() if nrhs else None
+    return bool(spd.value), ld.value, X, (Inv.reshape(n, n).T.copy() if want_inverse else None)

@@ -33,6 +33,56 @@ int gpx_dgemm_splitk(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, double
                      int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
                      int flags, double* work, int64_t work_doubles);
 
+
+/* ---- the hot path: objective + gradient, _setK, predict ------------------------------------- */
+typedef struct gpx_ctx gpx_ctx;
+enum { GPX_MODEL_EXACT = 0, GPX_MODEL_FITC = 1, GPX_MODEL_VFE = 2 };
+enum { GPX_COV_SE_ARD = 0, GPX_COV_SE_ISO = 1 }; /* GP.h:17-21 CovFunc */
+
+/* One context per GPU / per GP object (GP.h:14: one GP instance owns its data and solvers).
+ * Not re-entrant, like the reference object (GP.cpp:129 mutates the shared solver). */
+int gpx_ctx_create(int device, gpx_ctx** out);
+int gpx_ctx_destroy(gpx_ctx* ctx);
+
+/* GP::GP(train_in, train_out) (GP.cpp:20-37) and add_data (GP.cpp:43-55): uploads HOST X (d x n
+ * column-major) and y (n).  For row-sharded FITC/VFE each rank passes its own rows. */
+int gpx_set_data(gpx_ctx* ctx, const double* X, const double* y, int64_t n, int64_t d);
+/* FITC::set_inducing / VFE::set_inducing (FITC.cpp:22-26, VFE.cpp:21-25): HOST U (d x m). */
+int gpx_set_inducing(gpx_ctx* ctx, const double* U, int64_t m);
+
+/* Sum-all-reduce of `count` doubles at DEVICE pointer buf, in place, across the ranks that share
+ * the training rows (no reference counterpart: the reference is single-process).  Called from
+ * inside gpx_nll_grad / gpx_prepare for FITC and VFE after the library's stream has been
+ * synchronised; must return 0 after the reduced values are visible to later device work. */
+typedef int (*gpx_allreduce_fn)(double* buf, int64_t count, void* user);
+int gpx_set_allreduce(gpx_ctx* ctx, gpx_allreduce_fn fn, void* user);
+
+/* virtual GP::_calcNegLogProb(hyp, g, calc_grad) (GP.cpp:120-176), FITC::_calcNegLogProb
+ * (FITC.cpp:201-319), VFE::_calcNegLogProb (VFE.cpp:165-249).  hyp and grad are HOST vectors of
+ * length d+3 (ARD) / 4 (iso): [log l.., log sf, log sn, mean].  jitter = _jitter_u (sparse only).
+ * On numerical failure *nll = +inf and grad = +inf (exact, GP.cpp:132-134,170) or 0 (sparse,
+ * FITC.cpp:232, VFE.cpp:194); the return status stays 0. */
+int gpx_nll_grad(gpx_ctx* ctx, int model, int cov, const double* hyp, int calc_grad, double jitter,
+                 double* nll, double* grad);
+
+/* GP::_setK (GP.cpp:423-444), FITC::_setK (FITC.cpp:165-200), VFE::_setK (VFE.cpp:132-160):
+ * factor at the final hypers and cache alpha.  hyp is in/out for the exact model (noise
+ * escalation, GP.cpp:431-440), jitter is in/out for the sparse models (doubling loops). */
+int gpx_prepare(gpx_ctx* ctx, int model, int cov, double* hyp, double* jitter);
+
+/* GP::_predict / _predict_y / _predict_s2 (GP.cpp:273-334), FITC (FITC.cpp:109-164), VFE
+ * (VFE.cpp:113-131) without input gradients: HOST Xs (d x t); mu and/or s2 may be NULL. */
+int gpx_predict(gpx_ctx* ctx, const double* Xs, int64_t t, double* mu, double* s2);
+
+/* Cov::k (Cov/Cov.h:14; CovSEard.cpp:7-11, CovSEiso.cpp:6-11) on HOST buffers: x1 d x p, x2 d x q,
+ * K p x q column-major.  hyp holds at least the kernel hypers. */
+int gpx_cov_k(int cov, int64_t d, const double* hyp, const double* x1, int64_t p, const double* x2,
+              int64_t q, double* K);
+/* MatrixSolverLLT (MatrixSolver.cpp:6-29) on HOST buffers: A n x n column-major (lower read).
+ * *spd = check_SPD(); logdet, X = solve(B) (n x nrhs, in place) and Inv = inverse() are optional. */
+int gpx_chol_solve(int64_t n, const double* A, int* spd, double* logdet, double* B, int64_t nrhs,
+                   double* Inv);
+
 #ifdef __cplusplus
 }
 #endif

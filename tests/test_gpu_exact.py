@@ -1,0 +1,117 @@
+"""GPU parity tests of the exact-GP path against the CPU oracle (through the C ABI).
+
+Tolerances are the north star's: NLL rel <= 1e-9, gradient rel <= 1e-7 (max-norm relative),
+predictions rel <= 1e-9, all fp64.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from gp_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "refdata_small.npz")
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b)))
+
+
+@pytest.fixture(scope="module")
+def gpx():
+    from gp_amd import lib
+    return lib
+
+
+@pytest.mark.parametrize("shape", [(5, 3), (64, 64), (65, 130), (200, 77), (1000, 300)])
+@pytest.mark.parametrize("cov", [0, 1])
+def test_cov_k(gpx, cov, shape):
+    p, q = shape
+    d = 7
+    X1 = synth.make_inputs(3, p, d)
+    X2 = synth.make_inputs(4, q, d)
+    hyp = np.concatenate([0.3 * np.sin(np.arange(d)) + 0.5, [0.2]]) if cov == 0 else np.array([0.7, 0.2])
+    K = gpx.cov_k(cov, hyp, X1, X2)
+    Ko = oracle.cov_k(cov, hyp, X1, X2)
+    assert rel(K, Ko) < 1e-14
+    Kd = gpx.cov_k(cov, hyp, X1, X1)
+    assert np.all(np.diag(Kd) == np.exp(2 * hyp[-1]))   # direct differences: exact diagonal
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 65, 200, 513, 1500])
+def test_chol_solve_inverse_logdet(gpx, n):
+    rng = np.random.default_rng(n)
+    G = rng.normal(size=(n, n))
+    A = G @ G.T / n + np.eye(n)
+    B = rng.normal(size=(n, 3))
+    spd, ld, X, Inv = gpx.chol_solve(A, B, want_inverse=True)
+    assert spd
+    sign, ld_ref = np.linalg.slogdet(A)
+    assert abs(ld - ld_ref) <= 1e-11 * max(1.0, abs(ld_ref))
+    assert rel(X, np.linalg.solve(A, B)) < 1e-11
+    assert rel(Inv, np.linalg.inv(A)) < 1e-11
+    info, L = oracle.chol(A)
+    assert info == 0
+    A[n // 2, n // 2] = -1.0
+    assert not gpx.chol_solve(A)[0]                         # check_SPD() == false
+
+
+@pytest.mark.parametrize("cov", [0, 1])
+@pytest.mark.parametrize("n,d", [(50, 3), (300, 5), (1000, 10), (1537, 24)])
+def test_exact_nll_grad_vs_oracle(gpx, cov, n, d):
+    X, y, hyp, Xs = synth.make_problem(1, n, d, 33)
+    if cov == 1:
+        hyp = np.array([0.5 * np.log(d), 0.1, np.log(0.1), 0.05])
+    else:
+        hyp = hyp + np.concatenate([np.zeros(d), [0.1, 0.0, 0.05]])
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    nll, g = ctx.nll_grad(gpx.MODEL_EXACT, cov, hyp)
+    nll_o, g_o = oracle.exact_nll(cov, X, y, hyp)
+    assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
+    assert rel(g, g_o) <= 1e-7
+    assert ctx.nll_grad(gpx.MODEL_EXACT, cov, hyp, calc_grad=False) == nll
+    hyp2, _ = ctx.prepare(gpx.MODEL_EXACT, cov, hyp)
+    assert np.array_equal(hyp2, hyp)
+    mu, s2 = ctx.predict(Xs)
+    mu_o, s2_o = oracle.ExactState(cov, X, y, hyp).predict(Xs)
+    assert rel(mu, mu_o) <= 1e-9 and rel(s2, s2_o) <= 1e-9
+    ctx.close()
+
+
+def test_exact_golden_fixture(gpx):
+    g = np.load(GOLD)
+    ctx = gpx.Context()
+    ctx.set_data(g["X"], g["y"])
+    for cov, c in ((0, "ard"), (1, "iso")):
+        hyp = g[f"{c}_hyp"]
+        nll, gr = ctx.nll_grad(gpx.MODEL_EXACT, cov, hyp)
+        assert abs(nll - g[f"{c}_exact_nll"]) <= 1e-9 * abs(nll)
+        assert rel(gr, g[f"{c}_exact_grad"]) <= 1e-7
+        ctx.prepare(gpx.MODEL_EXACT, cov, hyp)
+        mu, s2 = ctx.predict(g["Xs"])
+        assert rel(mu, g[f"{c}_exact_mu"]) <= 1e-9 and rel(s2, g[f"{c}_exact_s2"]) <= 1e-9
+    ctx.close()
+
+
+def test_exact_failure_and_noise_escalation(gpx):
+    X, y, hyp, _ = synth.make_problem(2, 40, 3)
+    Xd, yd = np.vstack([X, X]), np.concatenate([y, y])
+    h = hyp.copy()
+    h[-2] = -np.inf                                   # zero noise on duplicated points: singular
+    ctx = gpx.Context()
+    ctx.set_data(Xd, yd)
+    nll, g = ctx.nll_grad(gpx.MODEL_EXACT, 0, h)
+    assert nll == np.inf and np.all(np.isinf(g))      # GP.cpp:132-134
+    h[-2] = np.log(1e-12)
+    h2, _ = ctx.prepare(gpx.MODEL_EXACT, 0, h)
+    st = oracle.ExactState(0, Xd, yd, h)
+    k = (h2[-2] - h[-2]) / np.log(np.sqrt(10))
+    assert h2[-2] > h[-2] and abs(k - round(k)) < 1e-9   # GP.cpp:431-440
+    assert abs(h2[-2] - st.hyp[-2]) < 1e-12 + 2 * np.log(np.sqrt(10))  # same loop; pivots may differ by one step
+    with pytest.raises(gpx.GpxError):
+        gpx.Context().predict(X)                      # predict before _setK (assert(_trained), GP.cpp:275)
+    ctx.close()
