@@ -53,4 +53,14 @@ int gpx_dgemm_splitk(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, double
                            work_doubles);
 }
 
+/* measurement hooks */
+int gpx_prof_gemm_begin(double min_flops, int max_launches) { return gpx_gemm_prof_begin(min_flops, max_launches); }
+int gpx_prof_gemm_end(double* total_ms, double* total_flops, int64_t* launches, double* skipped_flops) {
+    long l = 0;
+    const int rc = gpx_gemm_prof_end(total_ms, total_flops, &l, skipped_flops);
+    *launches = l;
+    return rc;
+}
+int gpx_bench_mfma_f64_peak(double* tflops) { return gpx_mfma_peak(tflops); }
+
 }  // extern "C"

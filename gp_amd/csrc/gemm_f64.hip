@@ -216,6 +216,28 @@ void launch(hipStream_t st, int a_kc, int b_kc, const GemmArgs& g, int grid) {
     else hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), dim3(grid), dim3(256), 0, st, g);
 }
 
+// ---- optional per-launch HIP-event timing of the large GEMMs (bench.py's roofline leg) -------
+struct GemmProf {
+    bool on = false;
+    double min_flops = 0;
+    std::vector<hipEvent_t> ev;  // pairs
+    std::vector<double> flops;
+    size_t used = 0;
+    double skipped_flops = 0;
+    long skipped = 0;
+} g_prof;
+
+double useful_flops(long M, long N, long K, int flags) {
+    double f = 2.0 * (double)M * (double)N * (double)K;
+    if (flags & GEMM_LOWER) f *= 0.5 * (1.0 + 1.0 / (double)((M + 127) / 128));
+    if (flags & (GEMM_KLO_M | GEMM_KLO_N | GEMM_KHI_M | GEMM_KHI_N)) {
+        // triangular operand: half of the K range on average; W^T W on lower tiles sums over
+        // k >= max(m, n): a third of the lower half (n^3/3 in all)
+        f *= (flags & GEMM_LOWER) ? 1.0 / 3.0 : 0.5;
+    }
+    return f;
+}
+
 int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
               const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
               int flags, int splitk, double* work) {
@@ -249,6 +271,17 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     }
     const long grid = (long)g.ntiles * g.splitk;
     if (grid > 0x7fffffffL) return GPX_ERR_ARG;
+    const double fl = useful_flops(M, N, K, flags);
+    bool timed = false;
+    if (g_prof.on) {
+        if (fl >= g_prof.min_flops && g_prof.used + 2 <= g_prof.ev.size()) {
+            timed = true;
+            (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+        } else {
+            g_prof.skipped_flops += fl;
+            g_prof.skipped++;
+        }
+    }
     if (bt == 128) launch<4, 4>(st, a_kc, b_kc, g, (int)grid);
     else launch<2, 2>(st, a_kc, b_kc, g, (int)grid);
     if (g.splitk > 1) {
@@ -257,11 +290,83 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
                            ldc, work, g.slab, g.splitk, (int)M, (int)N, beta,
                            (flags & GEMM_LOWER) ? bt : 0);
     }
+    if (timed) {
+        (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+        g_prof.flops.push_back(fl);
+        g_prof.used += 2;
+    }
     HIP_TRY(hipGetLastError());
     return GPX_OK;
 }
 
+// bare MFMA loop: what the matrix pipe delivers with operands in registers
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
+    v4d acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[(long)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 }  // namespace
+
+int gpx_gemm_prof_begin(double min_flops, int max_launches) {
+    if (g_prof.ev.size() < (size_t)max_launches * 2) {
+        const size_t old = g_prof.ev.size();
+        g_prof.ev.resize((size_t)max_launches * 2);
+        for (size_t i = old; i < g_prof.ev.size(); ++i) HIP_TRY(hipEventCreate(&g_prof.ev[i]));
+    }
+    g_prof.on = true;
+    g_prof.min_flops = min_flops;
+    g_prof.used = 0;
+    g_prof.flops.clear();
+    g_prof.skipped_flops = 0;
+    g_prof.skipped = 0;
+    return GPX_OK;
+}
+
+int gpx_gemm_prof_end(double* total_ms, double* total_flops, long* launches, double* skipped_flops) {
+    g_prof.on = false;
+    double ms = 0, fl = 0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        HIP_TRY(hipEventSynchronize(g_prof.ev[i + 1]));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
+        ms += t;
+        fl += g_prof.flops[i / 2];
+    }
+    *total_ms = ms;
+    *total_flops = fl;
+    *launches = (long)(g_prof.used / 2);
+    *skipped_flops = g_prof.skipped_flops;
+    return GPX_OK;
+}
+
+int gpx_mfma_peak(double* tflops) {
+    const int blocks = 256 * 2, iters = 40000;
+    double* out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out), (size_t)blocks * 256 * 8));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, out, 100);
+    HIP_TRY(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, out, iters);
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *tflops = (double)blocks * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
+    (void)hipFree(out);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return GPX_OK;
+}
 
 int gpx_gemm(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
              const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,

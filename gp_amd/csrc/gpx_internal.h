@@ -57,3 +57,8 @@ int gpx_gemm(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double 
 int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
                     const double* A, long lda, const double* B, long ldb, double beta, double* C,
                     long ldc, int flags, double* work, long work_doubles);
+
+// per-launch HIP-event timing of GEMM launches with >= min_flops useful flops (bench.py roofline)
+int gpx_gemm_prof_begin(double min_flops, int max_launches);
+int gpx_gemm_prof_end(double* total_ms, double* total_flops, long* launches, double* skipped_flops);
+int gpx_mfma_peak(double* tflops);

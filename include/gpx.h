@@ -34,6 +34,13 @@ int gpx_dgemm_splitk(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, double
                      int flags, double* work, int64_t work_doubles);
 
 
+/* ---- measurement hooks (no reference counterpart) ------------------------------------------ */
+/* HIP-event timing of every GEMM launch with >= min_flops useful flops, on the launch stream. */
+int gpx_prof_gemm_begin(double min_flops, int max_launches);
+int gpx_prof_gemm_end(double* total_ms, double* total_flops, int64_t* launches, double* skipped_flops);
+/* back-to-back v_mfma_f64_16x16x4_f64 from registers on every SIMD: the matrix pipe's ceiling */
+int gpx_bench_mfma_f64_peak(double* tflops);
+
 /* ---- the hot path: objective + gradient, _setK, predict ------------------------------------- */
 typedef struct gpx_ctx gpx_ctx;
 enum { GPX_MODEL_EXACT = 0, GPX_MODEL_FITC = 1, GPX_MODEL_VFE = 2 };
