@@ -1,5 +1,604 @@
-// sparse.hip — FITC / VFE objectives (placeholder until the next commit).
+// sparse.hip — FITC and VFE objectives, gradients, _setK and predict (FITC.cpp:109-319,
+// VFE.cpp:113-249), restructured into the O(n m^2) weight-matrix form of DESIGN.md §"Sparse":
+//
+//   phase 1 (row-local)  : Kxu, the n x m products, the m x m partial sums      -> all-reduce #1
+//   phase 2 (replicated) : A, its Cholesky, a = A^-1 F, log-dets, the NLL
+//   phase 3 (row-local)  : the weight matrix W_xu, sum_ab W_xu o dKxu/dtheta_i in one fused pass,
+//                          partial B^T diag(w) B                                   -> all-reduce #2
+//   phase 4 (replicated) : W_uu and sum W_uu o dKuu/dtheta_i
+//
+// Training rows may be sharded over ranks (one context per GPU holds its own rows); the two
+// all-reduces go through the callback given to gpx_set_allreduce (RCCL over xGMI in bench.py).
+// The per-hyper loops of the reference (FITC.cpp:269-308, VFE.cpp:213-237), which materialise
+// dKxu and an n x m x m product PER HYPER, become one pass that is independent of d.
 #include "ctx.h"
-int gpx_sparse_nll_grad(gpx_ctx*, int, int, const double*, int, double, double*, double*) { return GPX_ERR_UNSUPPORTED; }
-int gpx_sparse_prepare(gpx_ctx*, int, int, const double*, double*) { return GPX_ERR_UNSUPPORTED; }
-int gpx_sparse_predict(gpx_ctx*, const double*, long, double*, double*) { return GPX_ERR_UNSUPPORTED; }
+#include <cstring>
+#include <limits>
+
+namespace {
+
+const double INF = std::numeric_limits<double>::infinity();
+constexpr int PW = 8;  // partial sums per block
+
+// ---- block-partial helper ---------------------------------------------------------------------
+__device__ __forceinline__ void block_partials(double (&v)[PW], double* __restrict__ part) {
+    __shared__ double red[4][PW];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        double s = v[j];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (l == 0) red[w][j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < PW)
+        part[(long)blockIdx.x * PW + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void sum_partials_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out, int nout) {
+    __shared__ double red[256];
+    const int j = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += part[(long)b * PW + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && j < nout) out[j] = red[0];
+}
+
+// ---- FITC row kernels (one thread per training row; consecutive rows -> coalesced columns) ------
+// Gamma, 1/Gamma, p = r/Gamma, Ksc = diag(1/Gamma) Kxu   (FITC.cpp:215-216, 253-254)
+__global__ __launch_bounds__(256) void fitc_gamma_kernel(long n, long m, const double* __restrict__ V, long ld,
+                                                         const double* __restrict__ Kxu, const double* __restrict__ r,
+                                                         double sn2, double sf2, double* __restrict__ g,
+                                                         double* __restrict__ p, double* __restrict__ Ksc,
+                                                         double* __restrict__ part) {
+    const long a = (long)blockIdx.x * 256 + threadIdx.x;
+    double v[PW] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a < n) {
+        double s0 = 0.0, s1 = 0.0;
+        long b = 0;
+        for (; b + 1 < m; b += 2) {
+            const double x0 = V[a + b * ld], x1 = V[a + (b + 1) * ld];
+            s0 = fma(x0, x0, s0);
+            s1 = fma(x1, x1, s1);
+        }
+        if (b < m) s0 = fma(V[a + b * ld], V[a + b * ld], s0);
+        const double Gam = (sn2 + sf2 - (s0 + s1)) / sn2;
+        const double ig = 1.0 / Gam;
+        g[a] = ig;
+        p[a] = ig * r[a];
+        for (b = 0; b < m; ++b) Ksc[a + b * ld] = Kxu[a + b * ld] * ig;
+        v[0] = log(Gam);
+        v[1] = r[a] * (ig * r[a]);
+        v[2] = 1.0;
+    }
+    block_partials(v, part);
+}
+
+// c1 = rowsum(C o Ksc), q, pq = p - q, w and the trace coefficients; Bw = diag(w) B
+__global__ __launch_bounds__(256) void fitc_rowstats_kernel(long n, long m, const double* __restrict__ Cm,
+                                                            const double* __restrict__ Ksc, long ld,
+                                                            const double* __restrict__ Ka, const double* __restrict__ g,
+                                                            const double* __restrict__ p, double sn2,
+                                                            double* __restrict__ c2coef, double* __restrict__ ucoef,
+                                                            double* __restrict__ wv, double* __restrict__ part) {
+    const long a = (long)blockIdx.x * 256 + threadIdx.x;
+    double v[PW] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a < n) {
+        double s0 = 0.0, s1 = 0.0;
+        long b = 0;
+        for (; b + 1 < m; b += 2) {
+            s0 = fma(Cm[a + b * ld], Ksc[a + b * ld], s0);
+            s1 = fma(Cm[a + (b + 1) * ld], Ksc[a + (b + 1) * ld], s1);
+        }
+        if (b < m) s0 = fma(Cm[a + b * ld], Ksc[a + b * ld], s0);
+        const double c1 = s0 + s1;
+        const double q = g[a] * Ka[a];
+        const double pq = p[a] - q;
+        const double w = g[a] - c1 - pq * pq / sn2;
+        wv[a] = w;
+        c2coef[a] = -w / sn2;
+        ucoef[a] = -pq / sn2;
+        v[0] = g[a] - c1;
+        v[1] = pq * pq;
+        v[2] = pq;
+        v[3] = w;
+    }
+    block_partials(v, part);
+}
+
+__global__ __launch_bounds__(256) void rowscale_kernel(long n, long m, const double* __restrict__ in, long ld,
+                                                       const double* __restrict__ s, double* __restrict__ out) {
+    const long a = (long)blockIdx.x * 256 + threadIdx.x;
+    if (a >= n) return;
+    const double sa = s[a];
+    for (long b = 0; b < m; ++b) out[a + b * ld] = in[a + b * ld] * sa;
+}
+
+// alpha = (r - Ka)/sn2 (VFE.cpp:183) and its negation; partials: alpha^2, alpha, r^2 not needed here
+__global__ __launch_bounds__(256) void vfe_alpha_kernel(long n, const double* __restrict__ r, const double* __restrict__ Ka,
+                                                        double sn2, double* __restrict__ nalpha,
+                                                        double* __restrict__ part) {
+    const long a = (long)blockIdx.x * 256 + threadIdx.x;
+    double v[PW] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a < n) {
+        const double al = (r[a] - Ka[a]) / sn2;
+        nalpha[a] = -al;
+        v[0] = al * al;
+        v[1] = al;
+    }
+    block_partials(v, part);
+}
+
+__global__ __launch_bounds__(256) void vfe_rstats_kernel(long n, const double* __restrict__ r, double* __restrict__ part) {
+    const long a = (long)blockIdx.x * 256 + threadIdx.x;
+    double v[PW] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a < n) {
+        v[0] = r[a] * r[a];
+        v[2] = 1.0;
+    }
+    block_partials(v, part);
+}
+
+// ---- m x m kernels ---------------------------------------------------------------------------
+// out (lower) = ca*Kuu + cb*S + dadd*I
+__global__ void mm_combine_lower_kernel(long m, double ca, const double* __restrict__ Kuu, long ldk, double cb,
+                                        const double* __restrict__ S, long lds, double dadd, double* __restrict__ out,
+                                        long ldo) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * m) return;
+    const long i = idx % m, j = idx / m;
+    if (i < j) return;
+    double v = ca * Kuu[i + j * ldk] + cb * S[i + j * lds];
+    if (i == j) v += dadd;
+    out[i + j * ldo] = v;
+}
+// mirror the lower triangle into the upper one
+__global__ void mm_symmetrize_kernel(long m, double* __restrict__ A, long lda) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * m) return;
+    const long i = idx % m, j = idx / m;
+    if (i > j) A[j + i * lda] = A[i + j * lda];
+}
+// out = c1*A1 + c2*A2 + c3*a a^T + c4*A4   (full m x m; NULL matrices are skipped)
+__global__ void mm_combine_full_kernel(long m, double c1, const double* __restrict__ A1, long ld1, double c2,
+                                       const double* __restrict__ A2, long ld2, double c3, const double* __restrict__ a,
+                                       double c4, const double* __restrict__ A4, long ld4, double* __restrict__ out,
+                                       long ldo) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * m) return;
+    const long i = idx % m, j = idx / m;
+    double v = 0.0;
+    if (A1) v += c1 * A1[i + j * ld1];
+    if (A2) v += c2 * A2[i + j * ld2];
+    if (a) v += c3 * a[i] * a[j];
+    if (A4) v += c4 * A4[i + j * ld4];
+    out[i + j * ldo] = v;
+}
+// partial sums of A o B over the full m x m
+__global__ __launch_bounds__(256) void mm_inner_kernel(long m, const double* __restrict__ A, long lda,
+                                                       const double* __restrict__ B, long ldb, double* __restrict__ part) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    double v[PW] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (idx < m * m) {
+        const long i = idx % m, j = idx / m;
+        v[0] = A[i + j * lda] * B[i + j * ldb];
+    }
+    block_partials(v, part);
+}
+__global__ void dot_kernel(long m, const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < m; i += 256) s = fma(x[i], y[i], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+__global__ void predict_sparse_finish_kernel(long t, const double* __restrict__ ksa, const double* __restrict__ vu,
+                                             const double* __restrict__ vA, double mean, double sf2, double sn2,
+                                             int fitc, double* __restrict__ mu, double* __restrict__ s2) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= t) return;
+    if (mu) mu[j] = ksa[j] + mean;
+    if (s2) {
+        if (fitc) s2[j] = fmax(sn2 + (sf2 - (vu[j] - sn2 * vA[j])), sn2);  // FITC.cpp:117,153
+        else s2[j] = fmax(sf2 - (vu[j] - vA[j]), 0.0);                    // VFE.cpp:130
+    }
+}
+
+inline unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
+
+struct Sparse {
+    gpx_ctx* c;
+    hipStream_t st;
+    long n, m, ldn, ldm;
+    int d, model, cov;
+    HypView h;
+
+    int alloc(bool grad) {
+        int rc;
+        ldn = gpx_ld(n);
+        ldm = gpx_ld(m);
+        const long nm = ldn * m, mm = ldm * m;
+        if ((rc = c->Kxu.ensure(nm))) return rc;
+        if (model == GPX_MODEL_FITC) {
+            if ((rc = c->V.ensure(nm)) || (rc = c->Cm.ensure(nm))) return rc;  // Cm doubles as Ksc
+            if (grad && ((rc = c->Bm.ensure(nm)) || (rc = c->Tm.ensure(nm)))) return rc;
+        } else if (grad) {
+            if ((rc = c->Cm.ensure(nm))) return rc;
+        }
+        DevBuf* mb[] = {&c->Kuu, &c->Lu, &c->Am, &c->LA, &c->Winv_u, &c->Winv_A, &c->Kuu_inv, &c->A_inv, &c->Wuu};
+        for (DevBuf* b : mb)
+            if ((rc = b->ensure(mm))) return rc;
+        const long wdn = 64L * ((m + 63) / 64 * 64);
+        if ((rc = c->Wd_u.ensure(wdn)) || (rc = c->Wd_A.ensure(wdn))) return rc;
+        if ((rc = c->T.ensure(gpx_trtri_scratch(m) > 64 * mm ? gpx_trtri_scratch(m) : 64 * mm))) return rc;  // trtri scratch / split-K slabs
+        for (int i = 0; i < 8; ++i)
+            if ((rc = c->vn[i].ensure(n)) || (rc = c->vm[i].ensure(m + 16))) return rc;
+        if ((rc = c->red.ensure(m * m + m + GPX_MAX_DIM + 64))) return rc;
+        if ((rc = c->r.ensure(n))) return rc;
+        if ((rc = c->pred_tmp.ensure((long)PW * (nblk(n) > nblk(m * m) ? nblk(n) : nblk(m * m)) + 64))) return rc;
+        return GPX_OK;
+    }
+    double* part() { return c->pred_tmp.p; }
+    int finish_partials(long count, double* out, int nout) {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(PW), dim3(256), 0, st, part(), (int)nblk(count), out, nout);
+        return GPX_OK;
+    }
+    int allreduce(double* buf, long count) {
+        if (!c->allreduce) return GPX_OK;
+        HIP_TRY(hipStreamSynchronize(st));
+        return c->allreduce(buf, count, c->allreduce_user) ? GPX_ERR_STATE : GPX_OK;
+    }
+    // full symmetric inverse of a factored m x m matrix: Winv = L^-1, Inv = Winv^T Winv
+    int inverse(const double* L, const double* Wd, double* Winv, double* Inv, bool need_winv_only = false) {
+        int rc;
+        HIP_TRY(hipMemsetAsync(Winv, 0, (size_t)ldm * m * sizeof(double), st));
+        if ((rc = gpx_trtri(st, m, L, ldm, Wd, Winv, ldm, c->T.p))) return rc;
+        if (need_winv_only) return GPX_OK;
+        if ((rc = gpx_lauum(st, m, Winv, ldm, Inv, ldm))) return rc;
+        hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, Inv, ldm);
+        return GPX_OK;
+    }
+    // inputs, Kuu (+jitter on its diagonal) factored into Lu, Kxu
+    int kernels(double kuu_jitter) {
+        int rc;
+        if ((rc = gpx_scale_inputs(st, c->X.p, n, d, c->dpad, h.sc, c->Xt.p, c->ldx))) return rc;
+        if ((rc = gpx_scale_inputs(st, c->U.p, m, d, c->dpad, h.sc, c->Ut.p, c->ldu))) return rc;
+        if ((rc = gpx_cov_build(st, c->Ut.p, c->ldu, m, c->Ut.p, c->ldu, m, c->dpad, h.sf2, c->Kuu.p, ldm, 1, kuu_jitter)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(c->Lu.p, c->Kuu.p, (size_t)ldm * m * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemsetAsync(c->info, 0, 2 * sizeof(int), st));
+        if ((rc = gpx_potrf(st, m, c->Lu.p, ldm, c->Wd_u.p, c->info))) return rc;
+        if ((rc = gpx_cov_build(st, c->Xt.p, c->ldx, n, c->Ut.p, c->ldu, m, c->dpad, h.sf2, c->Kxu.p, ldn, 0, 0.0)))
+            return rc;
+        return gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p);
+    }
+};
+
+// scal layout (device c->scal.p, host c->host_scal)
+enum { S_LDU = 0, S_LDA = 1, S_FA = 2, S_TRKS = 3, S_TRAS = 4, S_P0 = 8 /* 8 partials */, S_TR0 = 32, S_TR1 = 32 + GPX_MAX_DIM + 8 };
+
+}  // namespace
+
+int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int calc_grad, double jitter,
+                        double* nll, double* grad) {
+    if (c->n <= 0 || c->m <= 0) return GPX_ERR_STATE;
+    c->prepared_model = -1;
+    Sparse s;
+    s.c = c; s.st = c->st; s.n = c->n; s.m = c->m; s.d = c->d; s.model = model; s.cov = cov;
+    int rc = parse_hyp(cov, c->d, hyp, s.h);
+    if (rc) return rc;
+    if ((rc = s.alloc(calc_grad != 0))) return rc;
+    const HypView& h = s.h;
+    const long n = s.n, m = s.m, ldn = s.ldn, ldm = s.ldm;
+    const int d = s.d, nh = h.nk + 2;
+    hipStream_t st = c->st;
+    const bool fitc = model == GPX_MODEL_FITC;
+    double* red = c->red.p;          // [m*m | m | tail]
+    double* redF = red + m * m;
+    double* redT = redF + m;
+    double* a_vec = c->vm[0].p;
+    double* g = c->vn[0].p;   // 1/Gamma
+    double* p = c->vn[1].p;   // r/Gamma
+    double* Ka = c->vn[2].p;
+    double* Ksc = c->Cm.p;    // FITC: diag(1/Gamma) Kxu, later reused
+    double* hs = c->host_scal;
+    *nll = INF;
+    if (calc_grad) memset(grad, 0, sizeof(double) * nh);  // FITC.cpp:232 / VFE.cpp:194 on failure
+
+    // ---- phase 1 ------------------------------------------------------------------------------
+    if ((rc = s.kernels(jitter))) return rc;
+    HIP_TRY(hipMemsetAsync(redT, 0, 16 * sizeof(double), st));
+    const double* Sop = fitc ? Ksc : c->Kxu.p;
+    if (fitc) {
+        // V = Kxu Lu^-T (FITC.cpp:213-215 via the factor: diag(Kxu Kuu^-1 Kux) = rowsum(V o V))
+        if ((rc = s.inverse(c->Lu.p, c->Wd_u.p, c->Winv_u.p, nullptr, true))) return rc;
+        if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->Winv_u.p, ldm, 0.0, c->V.p, ldn, GEMM_KHI_N)))
+            return rc;
+        hipLaunchKernelGGL(fitc_gamma_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, c->V.p, ldn, c->Kxu.p, c->r.p, h.sn2,
+                           h.sf2, g, p, Ksc, s.part());
+        s.finish_partials(n, redT, 3);  // sum log Gamma, r^T Gamma^-1 r, n_local
+        if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, p, 0.0, redF))) return rc;  // F = Kux Gamma^-1 r
+    } else {
+        hipLaunchKernelGGL(vfe_rstats_kernel, dim3(nblk(n)), dim3(256), 0, st, n, c->r.p, s.part());
+        s.finish_partials(n, redT, 3);  // r^T r, -, n_local
+        if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, c->r.p, 0.0, redF))) return rc;  // F = Kux r
+    }
+    // S = Kux [Gamma^-1] Kxu, lower tiles, split-K over the training rows (FITC.cpp:217, VFE.cpp:173)
+    if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, Sop, ldn, c->Kxu.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap)))
+        return rc;
+    if ((rc = s.allreduce(red, m * m + m + 16))) return rc;
+
+    // ---- phase 2 ------------------------------------------------------------------------------
+    // A = sn2*Kuu + S (FITC.cpp:217, VFE.cpp:174), factor, a = A^-1 F
+    hipLaunchKernelGGL(mm_combine_lower_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, h.sn2, c->Kuu.p, ldm, 1.0, red, m,
+                       0.0, c->Am.p, ldm);
+    HIP_TRY(hipMemcpyAsync(c->LA.p, c->Am.p, (size_t)ldm * m * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if ((rc = gpx_potrf(st, m, c->LA.p, ldm, c->Wd_A.p, c->info + 1))) return rc;
+    HIP_TRY(hipMemcpyAsync(a_vec, redF, m * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if ((rc = gpx_trsv(st, m, c->LA.p, ldm, c->Wd_A.p, a_vec, 0))) return rc;
+    if ((rc = gpx_trsv(st, m, c->LA.p, ldm, c->Wd_A.p, a_vec, 1))) return rc;
+    if ((rc = gpx_logdiag_sum(st, m, c->Lu.p, ldm, c->scal.p + S_LDU))) return rc;
+    if ((rc = gpx_logdiag_sum(st, m, c->LA.p, ldm, c->scal.p + S_LDA))) return rc;
+    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, st, m, redF, a_vec, c->scal.p + S_FA);
+    if (!fitc) {
+        // VFE needs Kuu^-1 for the trace term already in the NLL (VFE.cpp:181,188)
+        hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, red, m);
+        if ((rc = s.inverse(c->Lu.p, c->Wd_u.p, c->Winv_u.p, c->Kuu_inv.p))) return rc;
+        hipLaunchKernelGGL(mm_inner_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, c->Kuu_inv.p, ldm, red, m, s.part());
+        s.finish_partials(m * m, c->scal.p + S_TRKS, 1);
+    }
+    HIP_TRY(hipMemcpyAsync(hs, c->scal.p, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hs + 8, redT, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hs + 16, c->info, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int info[2];
+    memcpy(info, hs + 16, sizeof(info));
+    const double ntot = hs[8 + 2];
+    const double ldU = 2 * hs[S_LDU], ldA = 2 * hs[S_LDA], Fa = hs[S_FA];
+    double v, f_tr = 0.0;
+    if (fitc) {
+        const double data_fit = (hs[8 + 1] - Fa) / h.sn2;                                   // FITC.cpp:221-223
+        const double mc = ldA - ldU + hs[8 + 0] + (ntot - (double)m) * log(h.sn2);           // FITC.cpp:226
+        v = 0.5 * (data_fit + mc + ntot * log(2 * M_PI));
+        if (!(std::isfinite(data_fit) && std::isfinite(mc))) v = INF;
+    } else {
+        f_tr = 0.5 * (ntot * h.sf2 - hs[S_TRKS]) / h.sn2;                                    // VFE.cpp:188
+        v = 0.5 * ntot * log(2 * M_PI) + 0.5 * (ldA - ldU + (ntot - (double)m) * log(h.sn2)) +
+            0.5 * (hs[8 + 0] - Fa) / h.sn2 + f_tr;                                           // VFE.cpp:185-189
+    }
+    if (info[0] != 0 || info[1] != 0 || !std::isfinite(v)) return GPX_OK;  // NLL = INF, g = 0
+    *nll = v;
+    if (!calc_grad) return GPX_OK;
+
+    // ---- phase 3 ------------------------------------------------------------------------------
+    if ((rc = s.inverse(c->LA.p, c->Wd_A.p, c->Winv_A.p, c->A_inv.p))) return rc;
+    if ((rc = gpx_gemv_n(st, n, m, 1.0, c->Kxu.p, ldn, a_vec, 0.0, Ka))) return rc;  // Kxu a
+    TraceArgs ta = {};
+    ta.Xt1 = c->Xt.p; ta.ld1 = c->ldx; ta.p = n;
+    ta.Xt2 = c->Ut.p; ta.ld2 = c->ldu; ta.q = m;
+    ta.dpad = c->dpad;
+    ta.sf2 = h.sf2;
+    ta.v = a_vec;
+    HIP_TRY(hipMemsetAsync(redT, 0, (GPX_MAX_DIM + 32) * sizeof(double), st));
+    if (fitc) {
+        if ((rc = s.inverse(c->Lu.p, c->Wd_u.p, c->Winv_u.p, c->Kuu_inv.p))) return rc;
+        // C = Gamma^-1 Kxu A^-1 (FITC.cpp:262) and B = Kxu Kuu^-1 = V Lu^-1 (FITC.cpp:214)
+        double* Cm = c->Tm.p;
+        if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, Ksc, ldn, c->A_inv.p, ldm, 0.0, Cm, ldn, 0))) return rc;
+        if ((rc = gpx_gemm(st, 0, 1, n, m, m, 1.0, c->V.p, ldn, c->Winv_u.p, ldm, 0.0, c->Bm.p, ldn, GEMM_KLO_N))) return rc;
+        double* c2coef = c->vn[3].p;
+        double* ucoef = c->vn[4].p;
+        double* wv = c->vn[5].p;
+        hipLaunchKernelGGL(fitc_rowstats_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, Cm, Ksc, ldn, Ka, g, p, h.sn2,
+                           c2coef, ucoef, wv, s.part());
+        s.finish_partials(n, redT + GPX_MAX_DIM + 8, 4);  // sum(g-c1), sum pq^2, sum pq, sum w
+        // half of W_xu = C - (1/sn2) pq a^T - (1/sn2) diag(w) B, contracted with every dKxu at once
+        ta.M1 = Cm; ta.ldm1 = ldn;
+        ta.M2 = c->Bm.p; ta.ldm2 = ldn; ta.c2 = c2coef;
+        ta.u = ucoef;
+        if ((rc = gpx_pair_trace(st, ta, d, c->trace_ws.p, c->trace_ws.cap, redT))) return rc;
+        // B^T diag(w) B (signed weights: scaled copy, then the lower-tile split-K product)
+        hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, c->Bm.p, ldn, wv, Ksc);
+        if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, Ksc, ldn, c->Bm.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap)))
+            return rc;
+        if ((rc = s.allreduce(red, m * m + m + GPX_MAX_DIM + 32))) return rc;
+        hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, red, m);
+        // W_uu = sn2 A^-1 - Kuu^-1 + a a^T + B^T diag(w) B / sn2
+        hipLaunchKernelGGL(mm_combine_full_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, h.sn2, c->A_inv.p, ldm, -1.0,
+                           c->Kuu_inv.p, ldm, 1.0, a_vec, 1.0 / h.sn2, red, m, c->Wuu.p, ldm);
+    } else {
+        // P = A^-1 - Kuu^-1/sn2 ; W_xu = Kxu P - alpha a^T
+        hipLaunchKernelGGL(mm_combine_full_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, 1.0, c->A_inv.p, ldm,
+                           -1.0 / h.sn2, c->Kuu_inv.p, ldm, 0.0, (const double*)nullptr, 0.0, (const double*)nullptr, 0L,
+                           c->Wuu.p, ldm);
+        if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->Wuu.p, ldm, 0.0, c->Cm.p, ldn, 0))) return rc;
+        double* nalpha = c->vn[3].p;
+        hipLaunchKernelGGL(vfe_alpha_kernel, dim3(nblk(n)), dim3(256), 0, st, n, c->r.p, Ka, h.sn2, nalpha, s.part());
+        s.finish_partials(n, redT + GPX_MAX_DIM + 8, 2);  // sum alpha^2, sum alpha
+        ta.M1 = c->Cm.p; ta.ldm1 = ldn;
+        ta.u = nalpha;
+        if ((rc = gpx_pair_trace(st, ta, d, c->trace_ws.p, c->trace_ws.cap, redT))) return rc;
+        // tr(A^-1 S) and G = Kuu^-1 S Kuu^-1 use the reduced S (still in red[0..m*m), symmetrised)
+        hipLaunchKernelGGL(mm_inner_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, c->A_inv.p, ldm, red, m, s.part());
+        s.finish_partials(m * m, c->scal.p + S_TRAS, 1);
+        if ((rc = gpx_gemm(st, 0, 0, m, m, m, 1.0, c->Kuu_inv.p, ldm, red, m, 0.0, c->Am.p, ldm, 0))) return rc;
+        if ((rc = gpx_gemm(st, 0, 0, m, m, m, 1.0, c->Am.p, ldm, c->Kuu_inv.p, ldm, 0.0, c->LA.p, ldm, 0))) return rc;
+        if ((rc = s.allreduce(redT, GPX_MAX_DIM + 32))) return rc;
+        // W_uu = 0.5 [a a^T + sn2 A^-1 - Kuu^-1 + G/sn2]
+        hipLaunchKernelGGL(mm_combine_full_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, 0.5 * h.sn2, c->A_inv.p, ldm, -0.5,
+                           c->Kuu_inv.p, ldm, 0.5, a_vec, 0.5 / h.sn2, c->LA.p, ldm, c->Wuu.p, ldm);
+    }
+    // ---- phase 4: sum W_uu o dKuu_i (dKuu of the jittered Kuu: FITC.cpp:271, VFE.cpp:215) --------
+    TraceArgs tu = {};
+    tu.Xt1 = c->Ut.p; tu.ld1 = c->ldu; tu.p = m;
+    tu.Xt2 = c->Ut.p; tu.ld2 = c->ldu; tu.q = m;
+    tu.dpad = c->dpad;
+    tu.sf2 = h.sf2;
+    tu.M1 = c->Wuu.p; tu.ldm1 = ldm;
+    double* tuu = c->scal.p + S_TR0;
+    if ((rc = gpx_pair_trace(st, tu, d, c->trace_ws.p, c->trace_ws.cap, tuu))) return rc;
+    HIP_TRY(hipMemcpyAsync(hs + 32, tuu, (d + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hs + 32 + GPX_MAX_DIM + 8, redT, (GPX_MAX_DIM + 32) * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hs + 4, c->scal.p + S_TRAS, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const double* Suu = hs + 32;                         // [d | sum W K | tr W]
+    const double* Sxu = hs + 32 + GPX_MAX_DIM + 8;       // [d | sum W K | -]
+    const double* tail = Sxu + GPX_MAX_DIM + 8;
+    const double wx = fitc ? 2.0 : 1.0;   // FITC traced half of W_xu
+    const double fac = fitc ? 0.5 : 1.0;  // FITC: g = 0.5 * (...)
+    auto kern = [&](int i) { return fac * (Suu[i] + wx * Sxu[i]); };
+    if (cov == GPX_COV_SE_ARD) {
+        for (int i = 0; i < d; ++i) grad[i] = kern(i);
+    } else {
+        double t = 0;
+        for (int i = 0; i < d; ++i) t += kern(i);
+        grad[0] = t;
+    }
+    double gsf = fac * (2 * Suu[d] + 2 * jitter * Suu[d + 1] + wx * 2 * Sxu[d]);
+    if (fitc) {
+        gsf += 0.5 * (2 * h.sf2 * tail[3] / h.sn2);              // (1/sn2) w . dKnn  (CovSEard.cpp:90-96)
+        grad[nh - 2] = tail[0] - tail[1] / h.sn2;                 // FITC.cpp:311-313
+        grad[nh - 1] = -1 * tail[2] / h.sn2;                      // FITC.cpp:314
+    } else {
+        gsf += 0.5 * ntot * 2 * h.sf2 / h.sn2;                    // VFE.cpp:232-234
+        grad[nh - 2] = -1 * h.sn2 * tail[0] + (ntot - hs[4]) - 2 * f_tr;  // VFE.cpp:239
+        grad[nh - 1] = -1 * tail[1];                               // VFE.cpp:240
+    }
+    grad[h.nk - 1] = gsf;
+    return GPX_OK;
+}
+
+// FITC::_setK (FITC.cpp:165-200) and VFE::_setK (VFE.cpp:132-160)
+int gpx_sparse_prepare(gpx_ctx* c, int model, int cov, const double* hyp, double* jitter) {
+    if (c->n <= 0 || c->m <= 0) return GPX_ERR_STATE;
+    c->prepared_model = -1;
+    Sparse s;
+    s.c = c; s.st = c->st; s.n = c->n; s.m = c->m; s.d = c->d; s.model = model; s.cov = cov;
+    int rc = parse_hyp(cov, c->d, hyp, s.h);
+    if (rc) return rc;
+    if ((rc = s.alloc(false))) return rc;
+    const HypView& h = s.h;
+    const long n = s.n, m = s.m, ldn = s.ldn, ldm = s.ldm;
+    hipStream_t st = c->st;
+    const bool fitc = model == GPX_MODEL_FITC;
+    double* red = c->red.p;
+    double* redF = red + m * m;
+    double* a_vec = c->vm[0].p;
+    double cum = 0.0;  // VFE: jitter accumulated on Kuu's diagonal
+    for (int iter = 0; iter < 200; ++iter) {
+        const bool first = iter == 0;
+        double kuu_add;
+        if (fitc) {
+            if (!first) *jitter *= 2;                      // FITC.cpp:186
+            kuu_add = *jitter;                             // _u_solver->decomp(Kuu + jitter*I)
+        } else {
+            if (!first) cum += *jitter;                    // VFE.cpp:149 (cumulative)
+            kuu_add = cum;
+        }
+        if ((rc = s.kernels(kuu_add))) return rc;
+        if (fitc) {
+            if ((rc = s.inverse(c->Lu.p, c->Wd_u.p, c->Winv_u.p, nullptr, true))) return rc;
+            if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->Winv_u.p, ldm, 0.0, c->V.p, ldn, GEMM_KHI_N)))
+                return rc;
+            hipLaunchKernelGGL(fitc_gamma_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, c->V.p, ldn, c->Kxu.p, c->r.p,
+                               h.sn2, h.sf2, c->vn[0].p, c->vn[1].p, c->Cm.p, s.part());
+            if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, c->vn[1].p, 0.0, redF))) return rc;
+            if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Cm.p, ldn, c->Kxu.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p,
+                                      c->T.cap)))
+                return rc;
+        } else {
+            if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, c->r.p, 0.0, redF))) return rc;
+            if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Kxu.p, ldn, c->Kxu.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p,
+                                      c->T.cap)))
+                return rc;
+        }
+        if ((rc = s.allreduce(red, m * m + m))) return rc;
+        if (fitc) {
+            // A = sn2*Kuu(no jitter) + S, and A + jitter*I inside the retry loop (FITC.cpp:180,195-196)
+            const double dadd = -h.sn2 * kuu_add + (first ? 0.0 : *jitter);
+            hipLaunchKernelGGL(mm_combine_lower_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, h.sn2, c->Kuu.p, ldm, 1.0,
+                               red, m, dadd, c->LA.p, ldm);
+        } else {
+            // A = Kuu + Kux Kxu / sn2 (VFE.cpp:142,150)
+            hipLaunchKernelGGL(mm_combine_lower_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, 1.0, c->Kuu.p, ldm,
+                               1.0 / h.sn2, red, m, 0.0, c->LA.p, ldm);
+        }
+        if ((rc = gpx_potrf(st, m, c->LA.p, ldm, c->Wd_A.p, c->info + 1))) return rc;
+        int info[2];
+        HIP_TRY(hipMemcpyAsync(info, c->info, sizeof(info), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (!fitc && !first) *jitter *= 2;                 // VFE.cpp:156
+        if (info[0] == 0 && info[1] == 0) {
+            // _alpha = A^-1 Kux Gamma^-1 r (FITC.cpp:199) / A^-1 Kux r / sn2 (VFE.cpp:159)
+            HIP_TRY(hipMemcpyAsync(a_vec, redF, m * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if ((rc = gpx_trsv(st, m, c->LA.p, ldm, c->Wd_A.p, a_vec, 0))) return rc;
+            if ((rc = gpx_trsv(st, m, c->LA.p, ldm, c->Wd_A.p, a_vec, 1))) return rc;
+            if (!fitc) {
+                if ((rc = gpx_vec_shift(st, m, a_vec, 0.0, 1.0 / h.sn2, c->vm[1].p))) return rc;
+                HIP_TRY(hipMemcpyAsync(a_vec, c->vm[1].p, m * sizeof(double), hipMemcpyDeviceToDevice, st));
+            }
+            HIP_TRY(hipStreamSynchronize(st));
+            c->prepared_model = model;
+            c->prepared_cov = cov;
+            c->prepared_hyp.assign(hyp, hyp + h.nk + 2);
+            c->prepared_jitter = *jitter;
+            return GPX_OK;
+        }
+    }
+    return GPX_ERR_STATE;
+}
+
+int gpx_sparse_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double* s2) {
+    const long m = c->m;
+    const int d = c->d;
+    const bool fitc = c->prepared_model == GPX_MODEL_FITC;
+    HypView h;
+    int rc = parse_hyp(c->prepared_cov, d, c->prepared_hyp.data(), h);
+    if (rc) return rc;
+    hipStream_t st = c->st;
+    const long chunk = 16384;
+    const long ldm = gpx_ld(m), ldt = gpx_ld(chunk);
+    if ((rc = c->pred_K.ensure(2 * ldm * chunk)) || (rc = c->pred_xs.ensure((long)d * chunk)) ||
+        (rc = c->pred_xst.ensure((long)c->dpad * ldt)) || (rc = c->pred_out.ensure(5 * chunk)))
+        return rc;
+    double* K1 = c->pred_K.p;
+    double* K2 = c->pred_K.p + ldm * chunk;
+    double* d_ksa = c->pred_out.p;
+    double* d_vu = d_ksa + chunk;
+    double* d_vA = d_vu + chunk;
+    double* d_mu = d_vA + chunk;
+    double* d_s2 = d_mu + chunk;
+    for (long t0 = 0; t0 < t; t0 += chunk) {
+        const long tc = t - t0 < chunk ? t - t0 : chunk;
+        HIP_TRY(hipMemcpyAsync(c->pred_xs.p, Xs + t0 * d, (size_t)tc * d * sizeof(double), hipMemcpyHostToDevice, st));
+        if ((rc = gpx_scale_inputs(st, c->pred_xs.p, tc, d, c->dpad, h.sc, c->pred_xst.p, ldt))) return rc;
+        // K_star^T = k(U, Xs): m x tc   (FITC.cpp:114, VFE.cpp:116)
+        if ((rc = gpx_cov_build(st, c->Ut.p, c->ldu, m, c->pred_xst.p, ldt, tc, c->dpad, h.sf2, K1, ldm, 0, 0.0))) return rc;
+        if ((rc = gpx_gemv_t(st, m, tc, 1.0, K1, ldm, c->vm[0].p, 0.0, d_ksa))) return rc;
+        if (s2) {
+            // k*(Kuu^-1 - c A^-1)k*^T = |Lu^-1 k*|^2 - c |LA^-1 k*|^2   (FITC.cpp:115-117, VFE.cpp:129-130)
+            HIP_TRY(hipMemcpyAsync(K2, K1, (size_t)ldm * tc * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if ((rc = gpx_trsm_left(st, m, tc, c->Lu.p, ldm, c->Wd_u.p, K1, ldm, 0))) return rc;
+            if ((rc = gpx_trsm_left(st, m, tc, c->LA.p, ldm, c->Wd_A.p, K2, ldm, 0))) return rc;
+            if ((rc = gpx_colsumsq(st, m, tc, K1, ldm, d_vu))) return rc;
+            if ((rc = gpx_colsumsq(st, m, tc, K2, ldm, d_vA))) return rc;
+        }
+        hipLaunchKernelGGL(predict_sparse_finish_kernel, dim3(nblk(tc)), dim3(256), 0, st, tc, d_ksa, d_vu, d_vA, h.mean,
+                           h.sf2, h.sn2, fitc ? 1 : 0, mu ? d_mu : nullptr, s2 ? d_s2 : nullptr);
+        if (mu) HIP_TRY(hipMemcpyAsync(mu + t0, d_mu, tc * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (s2) HIP_TRY(hipMemcpyAsync(s2 + t0, d_s2, tc * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return GPX_OK;
+}
