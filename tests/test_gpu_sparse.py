@@ -115,8 +115,8 @@ def test_sparse_row_sharded_allreduce(gpx, model):
     mu_ref, s2_ref = ref.predict(Xs)
     for r in range(2):
         nll, g, mu, s2 = out[r]
-        assert abs(nll - nll_ref) <= 1e-11 * abs(nll_ref)
-        assert rel(g, g_ref) <= 1e-8
+        assert abs(nll - nll_ref) <= 1e-9 * abs(nll_ref)
+        assert rel(g, g_ref) <= 1e-7
         assert rel(mu, mu_ref) <= 1e-9 and rel(s2, s2_ref) <= 1e-9   # summation order differs across shards
     ref.close()
 
