@@ -2,10 +2,17 @@
 """bench.py — throughput of the GP training hot path on MI355X.
 
 One "step" = one NLL + hyper-gradient evaluation (one call of the reference's virtual
-_calcNegLogProb(hyp, g, true)), training data already resident in HBM, fixed evaluation hypers
-(SURVEY.md §8d).  Workload at N=1: the exact GP, n=65536 d=20 (BASELINE.json configs[2], the
-configuration the metric is quoted on).  The exact GP does not shard ("replicas only"), so with
---gpus N every rank runs one independent replica and `value` is their aggregate.
+_calcNegLogProb(hyp, g, true): GP.cpp:120, FITC.cpp:201, VFE.cpp:165), training data already
+resident in HBM, fixed evaluation hypers.
+
+  * headline (`value`): exact GP SE-ARD, n=65536 d=20 (BASELINE.json configs[2], the configuration
+    the metric is quoted on).  The exact GP does not shard ("replicas only"): with --gpus N every
+    rank runs one independent replica and `value` is their aggregate (weak scaling).
+  * `fitc` (and `vfe` with --workload all|vfe): the sparse models with the training rows sharded
+    over the N ranks and the m x m / m-vector partials summed by RCCL all-reduce (STRONG scaling:
+    n is fixed, BASELINE.json configs[3], [4]); reported in the same JSON line.
+
+Launch: `python bench.py` (N=1) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -21,9 +28,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (public spec)
+METRIC = "NLL+grad evals/sec: exact GP n=65536 d=20; FITC n=1M m=1024; % fp64 peak"
 
 
-def cpu_baseline_exact(d, n_sample=2048, n_target=65536):
+def cpu_baseline_exact(d, n_sample, n_target):
     """The oracle (a scalar single-thread C port of the reference's literal operation order) timed
     on a bounded sample: one NLL+grad evaluation at n_sample, scaled by n^3 to the target n."""
     import oracle
@@ -35,7 +43,95 @@ def cpu_baseline_exact(d, n_sample=2048, n_target=65536):
     scale = (n_target / n_sample) ** 3
     return {"value": 1.0 / (dt * scale), "unit": "evals/s", "cores": 1, "kind": "port",
             "sample": f"1 NLL+grad eval of the exact GP at n={n_sample} d={d} took {dt:.2f} s on 1 host core "
-                      f"({1.0 / dt:.4f} evals/s); value is that scaled by (n/{n_target})^3 to n={n_target} (extrapolated)"}
+                      f"({1.0 / dt:.4f} evals/s); value is that scaled by ({n_sample}/{n_target})^3 to n={n_target} "
+                      f"(extrapolated; the reference as shipped is single-threaded, CMakeLists.txt:12)"}
+
+
+class Dist:
+    """torch.distributed (backend nccl == RCCL) only when WORLD_SIZE > 1."""
+
+    def __init__(self):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.torch = None
+        self.dist = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            self.torch, self.dist = torch, dist
+
+    def allreduce_ptr(self, ptr, count):
+        """in-place sum all-reduce of `count` doubles at a raw device pointer (RCCL over xGMI)"""
+        torch = self.torch
+
+        class _Mem:
+            __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+        t = torch.as_tensor(_Mem(), device=torch.device("cuda", self.local_rank))
+        self.dist.all_reduce(t)
+        torch.cuda.current_stream().synchronize()
+
+    def sync(self, lib):
+        lib.check(lib.lib.gpx_device_synchronize(), "sync")
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def timed(D, lib, fn, steps, warmup, prof_min_flops):
+    out = None
+    for _ in range(warmup):
+        out = fn()
+    lib.check(lib.lib.gpx_prof_gemm_begin(C.c_double(prof_min_flops), 8192), "prof_begin")
+    D.sync(lib)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    D.sync(lib)
+    dt = time.perf_counter() - t0
+    ms_, fl_, sk_, nl_ = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int64(0)
+    lib.check(lib.lib.gpx_prof_gemm_end(C.byref(ms_), C.byref(fl_), C.byref(nl_), C.byref(sk_)), "prof_end")
+    prof = {"gemm_ms": ms_.value / steps, "gemm_flops": fl_.value / steps, "launches": int(nl_.value) // max(steps, 1),
+            "small_flops": sk_.value / steps}
+    return D.max_over_ranks(dt), out, prof
+
+
+def run_exact(D, lib, synth, n, d, steps, warmup):
+    X, y, hyp, _ = synth.make_problem(2, n, d)
+    ctx = lib.Context(D.local_rank)
+    ctx.set_data(X, y)
+    dt, (nll, g), prof = timed(D, lib, lambda: ctx.nll_grad(lib.MODEL_EXACT, lib.COV_SE_ARD, hyp), steps, warmup, 1e9)
+    ctx.close()
+    return dt, nll, prof
+
+
+def run_sparse(D, lib, synth, model, n, m, d, steps, warmup, cfg_index):
+    seed = 20240601 + cfg_index
+    hyp = synth.eval_hyps(d)
+    r0 = (n * D.rank) // D.world
+    r1 = (n * (D.rank + 1)) // D.world
+    X = synth.make_inputs(seed, r1 - r0, d, start_point=r0)
+    y = synth.make_targets(seed, X, hyp, start_point=r0)
+    U = synth.make_inputs(seed, m, d, start_point=0)   # inducing points: the first m training points
+    ctx = lib.Context(D.local_rank)
+    ctx.set_data(X, y)
+    ctx.set_inducing(U)
+    if D.world > 1:
+        ctx.set_allreduce(D.allreduce_ptr)
+    M = lib.MODEL_FITC if model == "fitc" else lib.MODEL_VFE
+    jitter = 1e-8   # (0.1 * noise_lb)^2 with the default noise_lb = 1e-3 (FITC.cpp:30, GP.cpp:28)
+    dt, (nll, g), prof = timed(D, lib, lambda: ctx.nll_grad(M, lib.COV_SE_ARD, hyp, jitter=jitter), steps, warmup, 1e8)
+    ctx.close()
+    return dt, nll, prof
 
 
 def main():
@@ -43,84 +139,71 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="default", choices=["default", "exact", "fitc", "vfe", "all"])
     ap.add_argument("--n", type=int, default=65536)
     ap.add_argument("--d", type=int, default=20)
+    ap.add_argument("--fitc-n", type=int, default=1 << 20)
+    ap.add_argument("--fitc-m", type=int, default=1024)
+    ap.add_argument("--vfe-n", type=int, default=1 << 22)
+    ap.add_argument("--vfe-m", type=int, default=2048)
+    ap.add_argument("--vfe-d", type=int, default=50)
+    ap.add_argument("--sparse-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
+    D = Dist()
     from gp_amd import lib, synth
-    n, d = args.n, args.d
-    X, y, hyp, _ = synth.make_problem(2, n, d)
-    ctx = lib.Context(local_rank)
-    ctx.set_data(X, y)
+    want = {"default": ("exact", "fitc"), "all": ("exact", "fitc", "vfe")}.get(args.workload, (args.workload,))
+    out = {"metric": METRIC, "unit": "evals/s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
 
-    def sync():
-        lib.check(lib.lib.gpx_device_synchronize(), "sync")
-        if dist is not None:
-            dist.barrier()
-            import torch
-            torch.cuda.synchronize()
-
-    nll = None
-    for _ in range(args.warmup):
-        nll, g = ctx.nll_grad(lib.MODEL_EXACT, lib.COV_SE_ARD, hyp)
-    # HIP-event timing of every large GEMM launch inside the timed region, on the launch stream
-    lib.check(lib.lib.gpx_prof_gemm_begin(C.c_double(1e9), 8192), "prof_begin")
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        nll, g = ctx.nll_grad(lib.MODEL_EXACT, lib.COV_SE_ARD, hyp)
-    sync()
-    dt = time.perf_counter() - t0
-    ms_, fl_, sk_ = C.c_double(0), C.c_double(0), C.c_double(0)
-    nl_ = C.c_int64(0)
-    lib.check(lib.lib.gpx_prof_gemm_end(C.byref(ms_), C.byref(fl_), C.byref(nl_), C.byref(sk_)), "prof_end")
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    if rank == 0:
-        peak = C.c_double(0)
-        lib.check(lib.lib.gpx_bench_mfma_f64_peak(C.byref(peak)), "mfma_peak")
-        evals = args.steps * world
-        gemm_tf = fl_.value / (ms_.value * 1e-3) / 1e12 if ms_.value > 0 else 0.0
-        out = {
-            "metric": "NLL+grad evals/sec: exact GP n=65536 d=20; FITC n=1M m=1024; % fp64 peak",
-            "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+    if "exact" in want:
+        n, d = args.n, args.d
+        dt, nll, prof = run_exact(D, lib, synth, n, d, args.steps, args.warmup)
+        evals = args.steps * D.world
+        gemm_tf = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] > 0 else 0.0
+        alg_tf = float(n) ** 3 * args.steps / dt / 1e12   # per GPU
+        out.update({
+            "value": evals / dt, "ms_per_step": 1e3 * dt / args.steps, "scaling": "weak",
             "config": {"workload": f"exact GP SE-ARD NLL+grad, n={n} d={d} (BASELINE configs[2]); "
-                                   f"{world} independent replica(s)", "n": n, "d": d,
-                       "parallelism": "replicas" if world > 1 else "single"},
-            "nll": nll,
-            "algorithmic_tflops": (float(n) ** 3) * evals / dt / 1e12 / world,
-            "frac_fp64_peak_whole_eval": (float(n) ** 3) * evals / dt / 1e12 / world / FP64_MFMA_PEAK_TFLOPS,
+                                   f"{D.world} independent replica(s), one per GPU", "n": n, "d": d,
+                       "parallelism": "replicas" if D.world > 1 else "single"},
+            "nll": nll, "algorithmic_tflops_per_gpu": alg_tf, "frac_fp64_peak_whole_eval": alg_tf / FP64_MFMA_PEAK_TFLOPS,
             "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": gemm_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "gemm_kernel<4,4,*,*> (fp64 MFMA GEMM/SYRK/TRMM tiles)",
-                         "launches_timed": int(nl_.value), "gemm_ms_per_eval": ms_.value / args.steps,
-                         "flops_timed_per_eval": fl_.value / args.steps,
-                         "flops_in_untimed_small_launches_per_eval": sk_.value / args.steps,
-                         "measured_bare_mfma_f64_tflops": peak.value},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_exact(d, 2048, n)
+                         "kernel": "gemm_kernel<4,4,*,*> (fp64 MFMA GEMM/SYRK/TRMM tiles; all launches >= 1 GFLOP)",
+                         "launches_per_eval": prof["launches"], "kernel_ms_per_eval": prof["gemm_ms"],
+                         "algorithmic_flops_per_eval": prof["gemm_flops"],
+                         "flops_in_untimed_small_launches_per_eval": prof["small_flops"]},
+        })
+    for model in ("fitc", "vfe"):
+        if model not in want:
+            continue
+        n, m, d = (args.fitc_n, args.fitc_m, args.d) if model == "fitc" else (args.vfe_n, args.vfe_m, args.vfe_d)
+        dt, nll, prof = run_sparse(D, lib, synth, model, n, m, d, args.sparse_steps, 1, 3 if model == "fitc" else 4)
+        flops = (6.0 if model == "fitc" else 3.0) * n * m * m
+        tf = flops * args.sparse_steps / dt / 1e12
+        sub = {"value": args.sparse_steps / dt, "unit": "evals/s", "ms_per_step": 1e3 * dt / args.sparse_steps,
+               "scaling": "strong", "n_gpus": D.world, "steps": args.sparse_steps,
+               "config": {"workload": f"{model.upper()} SE-ARD NLL+grad, n={n} m={m} d={d}, rows sharded over "
+                                      f"{D.world} GPU(s), RCCL all-reduce of m x m partials", "n": n, "m": m, "d": d},
+               "nll": nll, "algorithmic_tflops_total": tf,
+               "frac_fp64_peak_per_gpu": tf / D.world / FP64_MFMA_PEAK_TFLOPS,
+               "gemm_ms_per_eval_rank0": prof["gemm_ms"]}
+        out[model] = sub
+        if "exact" not in want and "value" not in out:
+            out.update({"value": sub["value"], "ms_per_step": sub["ms_per_step"], "scaling": "strong",
+                        "config": sub["config"], "steps": args.sparse_steps})
+
+    if D.rank == 0:
+        peak = C.c_double(0)
+        lib.check(lib.lib.gpx_bench_mfma_f64_peak(C.byref(peak)), "mfma_peak")
+        out["measured_bare_mfma_f64_tflops"] = peak.value
+        if not args.no_cpu_baseline and D.world == 1 and "exact" in want:
+            out["cpu_baseline"] = cpu_baseline_exact(args.d, 2048, args.n)
         print(json.dumps(out))
-    ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    if D.dist is not None:
+        D.dist.destroy_process_group()
 
 
 if __name__ == "__main__":
