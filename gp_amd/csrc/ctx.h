@@ -52,6 +52,7 @@ struct gpx_ctx {
     std::vector<double> prepared_hyp;
     double prepared_jitter = 0;
     DevBuf pred_K, pred_xs, pred_xst, pred_out, pred_tmp;
+    DevBuf pLu, pLA, pWd_u, pWd_A, palpha, pUt;  // sparse _setK state, private copies (objective calls keep it valid)
 };
 
 struct HypView {

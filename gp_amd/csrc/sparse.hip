@@ -293,7 +293,7 @@ enum { S_LDU = 0, S_LDA = 1, S_FA = 2, S_TRKS = 3, S_TRAS = 4, S_P0 = 8 /* 8 par
 int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int calc_grad, double jitter,
                         double* nll, double* grad) {
     if (c->n <= 0 || c->m <= 0) return GPX_ERR_STATE;
-    c->prepared_model = -1;
+    if (c->prepared_model == GPX_MODEL_EXACT) c->prepared_model = -1;  // Xt is rescaled below
     Sparse s;
     s.c = c; s.st = c->st; s.n = c->n; s.m = c->m; s.d = c->d; s.model = model; s.cov = cov;
     int rc = parse_hyp(cov, c->d, hyp, s.h);
@@ -548,6 +548,17 @@ int gpx_sparse_prepare(gpx_ctx* c, int model, int cov, const double* hyp, double
                 if ((rc = gpx_vec_shift(st, m, a_vec, 0.0, 1.0 / h.sn2, c->vm[1].p))) return rc;
                 HIP_TRY(hipMemcpyAsync(a_vec, c->vm[1].p, m * sizeof(double), hipMemcpyDeviceToDevice, st));
             }
+            // private copies: later objective evaluations reuse Lu / LA / Ut as scratch
+            const long mm = ldm * m, wdn = 64L * ((m + 63) / 64 * 64), un = (long)c->dpad * c->ldu;
+            if ((rc = c->pLu.ensure(mm)) || (rc = c->pLA.ensure(mm)) || (rc = c->pWd_u.ensure(wdn)) ||
+                (rc = c->pWd_A.ensure(wdn)) || (rc = c->palpha.ensure(m)) || (rc = c->pUt.ensure(un)))
+                return rc;
+            HIP_TRY(hipMemcpyAsync(c->pLu.p, c->Lu.p, mm * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(c->pLA.p, c->LA.p, mm * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(c->pWd_u.p, c->Wd_u.p, wdn * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(c->pWd_A.p, c->Wd_A.p, wdn * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(c->palpha.p, a_vec, m * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(c->pUt.p, c->Ut.p, un * sizeof(double), hipMemcpyDeviceToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
             c->prepared_model = model;
             c->prepared_cov = cov;
@@ -584,13 +595,13 @@ int gpx_sparse_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double*
         HIP_TRY(hipMemcpyAsync(c->pred_xs.p, Xs + t0 * d, (size_t)tc * d * sizeof(double), hipMemcpyHostToDevice, st));
         if ((rc = gpx_scale_inputs(st, c->pred_xs.p, tc, d, c->dpad, h.sc, c->pred_xst.p, ldt))) return rc;
         // K_star^T = k(U, Xs): m x tc   (FITC.cpp:114, VFE.cpp:116)
-        if ((rc = gpx_cov_build(st, c->Ut.p, c->ldu, m, c->pred_xst.p, ldt, tc, c->dpad, h.sf2, K1, ldm, 0, 0.0))) return rc;
-        if ((rc = gpx_gemv_t(st, m, tc, 1.0, K1, ldm, c->vm[0].p, 0.0, d_ksa))) return rc;
+        if ((rc = gpx_cov_build(st, c->pUt.p, c->ldu, m, c->pred_xst.p, ldt, tc, c->dpad, h.sf2, K1, ldm, 0, 0.0))) return rc;
+        if ((rc = gpx_gemv_t(st, m, tc, 1.0, K1, ldm, c->palpha.p, 0.0, d_ksa))) return rc;
         if (s2) {
             // k*(Kuu^-1 - c A^-1)k*^T = |Lu^-1 k*|^2 - c |LA^-1 k*|^2   (FITC.cpp:115-117, VFE.cpp:129-130)
             HIP_TRY(hipMemcpyAsync(K2, K1, (size_t)ldm * tc * sizeof(double), hipMemcpyDeviceToDevice, st));
-            if ((rc = gpx_trsm_left(st, m, tc, c->Lu.p, ldm, c->Wd_u.p, K1, ldm, 0))) return rc;
-            if ((rc = gpx_trsm_left(st, m, tc, c->LA.p, ldm, c->Wd_A.p, K2, ldm, 0))) return rc;
+            if ((rc = gpx_trsm_left(st, m, tc, c->pLu.p, ldm, c->pWd_u.p, K1, ldm, 0))) return rc;
+            if ((rc = gpx_trsm_left(st, m, tc, c->pLA.p, ldm, c->pWd_A.p, K2, ldm, 0))) return rc;
             if ((rc = gpx_colsumsq(st, m, tc, K1, ldm, d_vu))) return rc;
             if ((rc = gpx_colsumsq(st, m, tc, K2, ldm, d_vA))) return rc;
         }

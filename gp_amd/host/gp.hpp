@@ -1,0 +1,146 @@
+// gp.hpp — GP / FITC / VFE with the reference's class API (GP.h:14-122, FITC.h, VFE.h), host C++
+// over the C ABI of libgpx.so.  Training data lives on the GPU from construction; the virtual
+// _calcNegLogProb / _setK / _predict* hooks (seam (3)) each make ONE library call.
+//
+// Deviations from the reference, all deliberate:
+//  * MatrixDecomp::QR selects the same Cholesky as ::Cholesky (SPD inputs).
+//  * _check_SPD's eigenvalue / |I - K K^-1| test (GP.cpp:445-461) is replaced by "every Cholesky
+//    pivot > 0"; the noise / jitter escalation loops are reproduced as coded.
+//  * train() uses the built-in bounded L-BFGS (optimizer.hpp) instead of NLopt LD_SLSQP, and
+//    select_init_hyp() (MVMO, an un-vendored submodule of the reference) falls back to a
+//    deterministic scan over the bounds' interior.  Same budgets (160/130/150 evaluations).
+//  * predict*_with_grad (input gradients) are not provided yet.
+#pragma once
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+#include "cov.hpp"
+#include "dense.hpp"
+#include "matrix_solver.hpp"
+
+struct gpx_ctx;
+
+namespace gpx {
+
+class GP {
+public:
+    enum CovFunc { COV_SE_ARD, COV_SE_ISO };
+    enum MatrixDecomp { Cholesky, QR };
+
+protected:
+    MatrixXd _train_in;   // dim x num_data
+    VectorXd _train_out;  // num_data
+    CovFunc _cf;
+    MatrixDecomp _md;
+    Cov* _cov;
+    std::size_t _num_train;
+    double _noise_lb;
+    const std::size_t _dim;
+    const std::size_t _num_hyp;
+    VectorXd _hyps, _hyps_lb, _hyps_ub;
+    bool _fixhyps = false;
+    bool _noise_free = false;
+    bool _trained;
+    int _max_eval = 160;       // GP.cpp:232
+    std::string _last_status;  // optimiser status of the last train()
+    gpx_ctx* _ctx = nullptr;
+    bool _uploaded = false;
+
+    virtual int _model() const;  // GPX_MODEL_*
+    virtual double _jitter() const { return 0.0; }
+    virtual void _init();
+    virtual void _setK();
+    void _upload();
+    double _calcNegLogProb(const std::vector<double>&, std::vector<double>& g) const;
+    double _calcNegLogProb(const VectorXd& hyp) const;
+    double _calcNegLogProb(const VectorXd& hyp, VectorXd&) const;
+    virtual double _calcNegLogProb(const VectorXd& hyp, VectorXd& g, bool calc_grad) const;
+    virtual void _predict(const MatrixXd& x, VectorXd* y, VectorXd* s2) const;
+    void _set_hyp_range();
+    VectorXd vec2hyp(const std::vector<double>& vx) const;
+    std::vector<double> hyp2vec(const VectorXd& vx) const;
+    double _hyp_sn2(const VectorXd& hyp) const;
+    double _hyp_mean(const VectorXd& hyp) const;
+    double _likelihood_gradient_checking(const VectorXd& hyp, const VectorXd& grad);
+    static double _objective(const std::vector<double>& x, std::vector<double>& g, void* data);
+
+public:
+    GP(const MatrixXd& train_in, const MatrixXd& train_out, CovFunc cf = COV_SE_ARD, MatrixDecomp md = Cholesky);
+    virtual ~GP();
+    GP(const GP&) = delete;
+    GP& operator=(const GP&) = delete;
+    void add_data(const MatrixXd& train_in, const MatrixXd& train_out);
+
+    std::size_t dim() const noexcept { return _dim; }
+    std::size_t num_hyp() const noexcept { return _num_hyp; }
+    std::size_t num_train() const noexcept { return _num_train; }
+    VectorXd get_default_hyps() const noexcept;
+    const MatrixXd& train_in() const noexcept { return _train_in; }
+    const VectorXd& train_out() const noexcept { return _train_out; }
+    bool trained() const noexcept { return _trained; }
+    bool noise_free() const { return _noise_free; }
+    void set_noise_lower_bound(double) noexcept;
+    void set_fixed(bool f) { _fixhyps = f; }
+    void set_noise_free(bool flag);
+    const std::string& last_optimizer_status() const { return _last_status; }
+
+    virtual double train(const VectorXd& init_hyps);
+    double train();
+    const VectorXd& get_hyp() const noexcept { return _hyps; }
+    // analytic NLL + gradient at hyp (what the optimiser sees) and the relative error of the
+    // gradient against central differences (GP.cpp:486-507, FITC::test_obj, VFE::test_obj)
+    double nll(const VectorXd& hyp, VectorXd& grad) const { return _calcNegLogProb(hyp, grad, true); }
+    double check_gradient(const VectorXd& hyp, double eps = 1e-3);
+
+    double predict_y(const VectorXd& xs) const;
+    double predict_s2(const VectorXd& xs) const;
+    void predict(const VectorXd& xs, double& y, double& s2) const;
+    std::tuple<double, double> predict(const VectorXd& xs) const;
+    VectorXd batch_predict_y(const MatrixXd& xs) const;
+    VectorXd batch_predict_s2(const MatrixXd& xs) const;
+    void batch_predict(const MatrixXd& xs, VectorXd& y, VectorXd& s2) const;
+    VectorXd select_init_hyp(std::size_t max_eval, const VectorXd& def_hyp);
+};
+
+class SparseGP : public GP {
+protected:
+    MatrixXd _inducing;
+    std::size_t _num_inducing;
+    double _jitter_u = 1e-8;
+    bool _inducing_uploaded = false;
+    double _jitter() const override { return _jitter_u; }
+    void _init() override;
+    void _setK() override;
+    void _upload_inducing();
+    double _calcNegLogProb(const VectorXd& hyp, VectorXd& g, bool calc_grad) const override;
+    SparseGP(const MatrixXd& train_in, const MatrixXd& train_out, CovFunc cf, MatrixDecomp md);
+
+public:
+    void set_inducing(const MatrixXd& u);
+    double train(const VectorXd& init_hyps) override;
+    using GP::train;
+    void test_obj(const VectorXd& hyp);  // prints [hyp, grad, grad_fd] and both timings
+};
+
+class FITC : public SparseGP {
+    int _model() const override;
+
+public:
+    FITC(const MatrixXd& train_in, const MatrixXd& train_out, CovFunc cf = COV_SE_ARD, MatrixDecomp md = QR)
+        : SparseGP(train_in, train_out, cf, md) { _max_eval = 130; }  // FITC.cpp:75
+};
+
+class VFE : public SparseGP {
+    int _model() const override;
+
+public:
+    VFE(const MatrixXd& train_in, const MatrixXd& train_out, CovFunc cf = COV_SE_ARD, MatrixDecomp md = QR)
+        : SparseGP(train_in, train_out, cf, md) { _max_eval = 150; }  // VFE.cpp:74
+};
+
+// whitespace text matrix IO of the demos (util.cpp:14-62, mygp.cpp:32-36)
+MatrixXd read_matrix(const std::string& path);
+void write_pred(const std::string& path, const VectorXd& mean, const VectorXd& s2);
+
+}  // namespace gpx

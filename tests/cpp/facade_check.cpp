@@ -1,0 +1,91 @@
+// facade_check.cpp — exercises the C++ facade (GP / FITC / VFE / Cov / MatrixSolver) on text data
+// in the current directory and prints `key value...` lines that tests/test_gpu_facade.py compares
+// with the oracle.  usage: facade_check <num_train> <num_inducing> <fixed 0|1>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include "../../gp_amd/host/gp.hpp"
+using namespace gpx;
+
+static void pv(const char* k, const VectorXd& v) {
+    std::printf("%s", k);
+    for (std::size_t i = 0; i < v.size(); ++i) std::printf(" %.17g", v[i]);
+    std::printf("\n");
+}
+
+template <class M>
+static void run(const char* tag, M& gp, const VectorXd& init, const MatrixXd& test_x, bool fixed) {
+    char key[64];
+    VectorXd g;
+    const double nll0 = gp.nll(init, g);
+    std::snprintf(key, sizeof key, "%s_nll0", tag); std::printf("%s %.17g\n", key, nll0);
+    std::snprintf(key, sizeof key, "%s_grad0", tag); pv(key, g);
+    std::snprintf(key, sizeof key, "%s_fdrel", tag); std::printf("%s %.17g\n", key, gp.check_gradient(init, 1e-4));
+    gp.set_fixed(fixed);
+    const double nll = gp.train(init);
+    std::snprintf(key, sizeof key, "%s_nll", tag); std::printf("%s %.17g\n", key, nll);
+    std::fprintf(stderr, "%s optimizer status: %s\n", tag, gp.last_optimizer_status().c_str());
+    std::snprintf(key, sizeof key, "%s_hyp", tag); pv(key, gp.get_hyp());
+    std::snprintf(key, sizeof key, "%s_mu", tag); pv(key, gp.batch_predict_y(test_x));
+    std::snprintf(key, sizeof key, "%s_s2", tag); pv(key, gp.batch_predict_s2(test_x));
+    double y1, s1;
+    gp.predict(test_x.col(0), y1, s1);
+    std::snprintf(key, sizeof key, "%s_single", tag); std::printf("%s %.17g %.17g\n", key, y1, s1);
+}
+
+int main(int argc, char** argv) {
+    const long n = argc > 1 ? atol(argv[1]) : 200, m = argc > 2 ? atol(argv[2]) : 32;
+    const bool fixed = argc > 3 ? atoi(argv[3]) != 0 : true;
+    const MatrixXd train_x = read_matrix("train_x").transpose();
+    const MatrixXd train_y = read_matrix("train_y");
+    const MatrixXd test_x = read_matrix("test_x").transpose();
+    MatrixXd y(n, 1);
+    for (long i = 0; i < n; ++i) y(i, 0) = train_y(i, 0);
+    const MatrixXd X = train_x.leftCols(n);
+    {
+        GP gp(X, y, GP::COV_SE_ARD, GP::QR);
+        VectorXd init = gp.get_default_hyps();
+        pv("default_hyp", init);
+        init[init.size() - 2] = std::log(0.1 * stddev(y.data(), n));
+        run("gp", gp, init, test_x, fixed);
+    }
+    {
+        FITC gp(X, y);
+        gp.set_inducing(train_x.rightCols(m));
+        VectorXd init = gp.get_default_hyps();
+        init[init.size() - 2] = std::log(0.1 * stddev(y.data(), n));
+        run("fitc", gp, init, test_x, fixed);
+    }
+    {
+        VFE gp(X, y);
+        gp.set_inducing(train_x.rightCols(m));
+        VectorXd init = gp.get_default_hyps();
+        init[init.size() - 2] = std::log(0.1 * stddev(y.data(), n));
+        run("vfe", gp, init, test_x, fixed);
+    }
+    {   // seams (1) and (2)
+        CovSEiso cov(X.rows());
+        VectorXd h = {0.3, 0.1};
+        const MatrixXd K = cov.k(h, X.leftCols(5), X.leftCols(7));
+        VectorXd flat(std::vector<double>(K.data(), K.data() + K.size()));
+        pv("iso_k", flat);
+        CovSEard ard(X.rows());
+        VectorXd ha(X.rows() + 1, 0.5);
+        MatrixXd Kxx = ard.k(ha, X.leftCols(40), X.leftCols(40));
+        for (std::size_t i = 0; i < 40; ++i) Kxx(i, i) += 0.01;
+        MatrixSolverLLT llt;
+        llt.decomp(Kxx);
+        std::printf("llt_spd %d\nllt_logdet %.17g\n", (int)llt.check_SPD(), llt.log_det());
+        const MatrixXd inv = llt.inverse();
+        double err = 0;
+        for (std::size_t i = 0; i < 40; ++i)
+            for (std::size_t j = 0; j < 40; ++j) {
+                double s = 0;
+                for (std::size_t k = 0; k < 40; ++k) s += Kxx(i, k) * inv(k, j);
+                err = std::fmax(err, std::fabs(s - (i == j ? 1.0 : 0.0)));
+            }
+        std::printf("llt_inv_err %.3g\n", err);
+    }
+    return 0;
+}
