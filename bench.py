@@ -117,8 +117,8 @@ def run_exact(D, lib, synth, n, d, steps, warmup):
 def run_sparse(D, lib, synth, model, n, m, d, steps, warmup, cfg_index):
     seed = 20240601 + cfg_index
     hyp = synth.eval_hyps(d)
-    r0 = (n * D.rank) // D.world
-    r1 = (n * (D.rank + 1)) // D.world
+    from gp_amd.sharding import shard_range
+    r0, r1 = shard_range(n, D.rank, D.world)
     X = synth.make_inputs(seed, r1 - r0, d, start_point=r0)
     y = synth.make_targets(seed, X, hyp, start_point=r0)
     U = synth.make_inputs(seed, m, d, start_point=0)   # inducing points: the first m training points
