@@ -68,6 +68,53 @@ __global__ __launch_bounds__(256) void potrf_base_kernel(double* __restrict__ A,
     }
 }
 
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// One WAVE factors a 64x64 (identity-padded) diagonal block held in registers: lane i owns row i.
+// Column values are broadcast with v_readlane (no LDS, no barriers).  Writes L over the lower
+// triangle of A and W = L^-1 (lower, zeros above) to W with leading dimension ldw.
+__global__ __launch_bounds__(64) void potrf_base_reg_kernel(double* __restrict__ A, long lda, int nb,
+                                                            double* __restrict__ W, long ldw, int wfull,
+                                                            int* __restrict__ info) {
+    const int i = threadIdx.x;
+    double a[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) a[k] = (i < nb && k < nb && k <= i) ? A[i + (long)k * lda] : ((i == k) ? 1.0 : 0.0);
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double piv = lane_bcast(a[j], j);
+        bad = bad || !(piv > 0.0);  // Eigen::LLT: NumericalIssue on a pivot <= 0
+        const double rs = sqrt(piv);
+        a[j] = (i == j) ? rs : a[j] / rs;
+#pragma unroll
+        for (int k = j + 1; k < NB; ++k) a[k] = fma(-a[j], lane_bcast(a[j], k), a[k]);
+    }
+    if (bad && i == 0) *info = 1;
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+        if (i < nb && k < nb && k <= i) A[i + (long)k * lda] = a[k];
+    // column c = lane of W = L^-1 by forward substitution; L_ik comes from lane i, register k
+    const int c = i;
+    double w[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) s = fma(-lane_bcast(a[k], r), w[k], s);
+        w[r] = s / lane_bcast(a[r], r);
+    }
+    const int lim = wfull ? NB : nb;
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+        if (r < lim && c < lim) W[r + (long)c * ldw] = (r >= c) ? w[r] : 0.0;
+}
+
 // B (M x nb) <- B * W^T with W = inverse of a base block (lower): the TRSM X L^T = B
 __global__ __launch_bounds__(256) void trsm_right_base_kernel(double* __restrict__ B, long ldb, long M, int nb,
                                                               const double* __restrict__ Wd) {
@@ -172,7 +219,7 @@ int trsm_right_rec(hipStream_t st, long M, long n1, const double* L, long ldl, c
 
 int potrf_rec(hipStream_t st, long n, double* A, long lda, double* Wd, int* info) {
     if (n <= NB) {
-        hipLaunchKernelGGL(potrf_base_kernel, dim3(1), dim3(256), 0, st, A, lda, (int)n, Wd, info);
+        hipLaunchKernelGGL(potrf_base_reg_kernel, dim3(1), dim3(64), 0, st, A, lda, (int)n, Wd, (long)NB, 1, info);
         return GPX_OK;
     }
     const long n1 = split(n), n2 = n - n1;
@@ -199,6 +246,32 @@ int trtri_rec(hipStream_t st, long n, const double* L, long ldl, double* W, long
     // W21 = -W22 * T     (W22 lower: A(m,k) zero for k > m)
     return gpx_gemm(st, 0, 1, n2, n1, n2, -1.0, W + n1 + n1 * ldw, ldw, T, ldt, 0.0, W + n1, ldw,
                     GEMM_KHI_M | GEMM_HEAVY_LAST);
+}
+
+// Factor and invert in one recursion: on return the diagonal blocks of A hold those of L (the
+// off-diagonal blocks of A are NOT L) and W = L^-1.  L21 lives in W's (2,1) block until that block
+// is overwritten by W21, so there is no triangular solve and no small kernel besides the 64x64 base.
+int potrf_inv_rec(hipStream_t st, long n, double* A, long lda, double* W, long ldw, double* T, int* info) {
+    if (n <= NB) {
+        hipLaunchKernelGGL(potrf_base_reg_kernel, dim3(1), dim3(64), 0, st, A, lda, (int)n, W, ldw, 0, info);
+        return GPX_OK;
+    }
+    const long n1 = split(n), n2 = n - n1;
+    double* W21 = W + n1;
+    double* W22 = W + n1 + n1 * ldw;
+    int rc = potrf_inv_rec(st, n1, A, lda, W, ldw, T, info);
+    if (rc) return rc;
+    // L21 = A21 * W11^T   (B(n,k) = W11[n + k*ldw], zero for k > n)
+    rc = gpx_gemm(st, 0, 0, n2, n1, n1, 1.0, A + n1, lda, W, ldw, 0.0, W21, ldw, GEMM_KHI_N);
+    if (rc) return rc;
+    rc = gpx_gemm(st, 0, 0, n2, n2, n1, -1.0, W21, ldw, W21, ldw, 1.0, A + n1 + n1 * lda, lda, GEMM_LOWER);
+    if (rc) return rc;
+    rc = potrf_inv_rec(st, n2, A + n1 + n1 * lda, lda, W22, ldw, T, info);
+    if (rc) return rc;
+    const long ldt = gpx_ld(n2);
+    rc = gpx_gemm(st, 0, 1, n2, n1, n1, 1.0, W21, ldw, W, ldw, 0.0, T, ldt, GEMM_KLO_N);  // T = L21 W11
+    if (rc) return rc;
+    return gpx_gemm(st, 0, 1, n2, n1, n2, -1.0, W22, ldw, T, ldt, 0.0, W21, ldw, GEMM_KHI_M | GEMM_HEAVY_LAST);
 }
 
 int trsm_left_rec(hipStream_t st, long n, long nrhs, const double* L, long ldl, const double* Wd, double* B,
@@ -231,6 +304,14 @@ int trsm_left_rec(hipStream_t st, long n, long nrhs, const double* L, long ldl, 
 int gpx_potrf(hipStream_t st, long n, double* A, long lda, double* Wd, int* info) {
     if (n <= 0) return GPX_OK;
     const int rc = potrf_rec(st, n, A, lda, Wd, info);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return GPX_OK;
+}
+
+int gpx_potrf_inv(hipStream_t st, long n, double* A, long lda, double* W, long ldw, double* T, int* info) {
+    if (n <= 0) return GPX_OK;
+    const int rc = potrf_inv_rec(st, n, A, lda, W, ldw, T, info);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return GPX_OK;

@@ -108,15 +108,34 @@ int gpx_exact_nll_grad(gpx_ctx* c, int cov, const double* hyp, int calc_grad, do
     const int d = c->d;
     if (n <= 0) return GPX_ERR_STATE;
     HypView h;
-    int rc = factor_and_solve(c, cov, hyp, h);
-    if (rc) return rc;
+    int rc;
+    if (!calc_grad) {
+        if ((rc = factor_and_solve(c, cov, hyp, h))) return rc;
+    } else {
+        // gradient path: factor and invert in ONE recursion (W = L^-1), alpha = W^T (W r)
+        if ((rc = parse_hyp(cov, d, hyp, h))) return rc;
+        c->lda = gpx_ld(n);
+        if ((rc = c->A.ensure(c->lda * n)) || (rc = c->W.ensure(c->lda * n)) || (rc = c->T.ensure(gpx_trtri_scratch(n))) ||
+            (rc = c->r.ensure(n)) || (rc = c->alpha.ensure(n)) || (rc = c->nalpha.ensure(n)))
+            return rc;
+        if ((rc = gpx_scale_inputs(c->st, c->X.p, n, d, c->dpad, h.sc, c->Xt.p, c->ldx))) return rc;
+        HIP_TRY(hipMemsetAsync(c->info, 0, sizeof(int), c->st));
+        HIP_TRY(hipMemsetAsync(c->W.p, 0, (size_t)c->lda * n * sizeof(double), c->st));
+        if ((rc = gpx_cov_build(c->st, c->Xt.p, c->ldx, n, c->Xt.p, c->ldx, n, c->dpad, h.sf2, c->A.p, c->lda, 1, h.sn2)))
+            return rc;
+        if ((rc = gpx_potrf_inv(c->st, n, c->A.p, c->lda, c->W.p, c->lda, c->T.p, c->info))) return rc;
+        if ((rc = gpx_vec_shift(c->st, n, c->y.p, h.mean, 1.0, c->r.p))) return rc;
+        if ((rc = gpx_gemv_n(c->st, n, n, 1.0, c->W.p, c->lda, c->r.p, 0.0, c->nalpha.p, 1))) return rc;
+        if ((rc = gpx_gemv_t(c->st, n, n, 1.0, c->W.p, c->lda, c->nalpha.p, 0.0, c->alpha.p, 1))) return rc;
+        if ((rc = gpx_logdiag_sum(c->st, n, c->A.p, c->lda, c->scal.p))) return rc;
+        if ((rc = gpx_reduce3(c->st, n, c->r.p, c->alpha.p, c->scal.p + 1))) return rc;
+    }
     const int nh = h.nk + 2;
     // a prepared state survives only an NLL-only evaluation at the very same hypers
     if (!(c->prepared_model == GPX_MODEL_EXACT && !calc_grad && c->prepared_cov == cov &&
           (int)c->prepared_hyp.size() == nh && !memcmp(c->prepared_hyp.data(), hyp, nh * sizeof(double))))
         c->prepared_model = -1;
 
-    // NLL first (one small read-back), so a failed factorisation skips the O(n^3) inverse
     HIP_TRY(hipMemcpyAsync(c->host_scal, c->scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipMemcpyAsync(c->host_scal + 8, c->info, sizeof(int), hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
@@ -135,9 +154,6 @@ int gpx_exact_nll_grad(gpx_ctx* c, int cov, const double* hyp, int calc_grad, do
     if (!calc_grad) return GPX_OK;
 
     // Q = (K + sn2 I)^-1 - alpha alpha^T, g_i = 0.5 sum(Q o dK_i)   (GP.cpp:153-163)
-    if ((rc = c->W.ensure(c->lda * n)) || (rc = c->T.ensure(gpx_trtri_scratch(n)))) return rc;
-    HIP_TRY(hipMemsetAsync(c->W.p, 0, (size_t)c->lda * n * sizeof(double), c->st));
-    if ((rc = gpx_trtri(c->st, n, c->A.p, c->lda, c->Wd.p, c->W.p, c->lda, c->T.p))) return rc;
     if ((rc = gpx_lauum(c->st, n, c->W.p, c->lda, c->A.p, c->lda))) return rc;
     if ((rc = gpx_vec_shift(c->st, n, c->alpha.p, 0.0, -1.0, c->nalpha.p))) return rc;
     TraceArgs ta = {};

@@ -32,6 +32,9 @@ int gpx_pair_trace(hipStream_t st, TraceArgs g, int d, double* partial_ws, long 
 // ld 64) receives the inverse of every 64x64 diagonal base block; *info (device int, must be 0
 // on entry) is set to 1 when a pivot is not positive.
 int gpx_potrf(hipStream_t st, long n, double* A, long lda, double* Wd, int* info);
+// Factor AND invert: diagonal blocks of A <- those of L (off-diagonal blocks of A are scratch),
+// W <- L^-1.  W must be zero above the diagonal on entry; T as for gpx_trtri.
+int gpx_potrf_inv(hipStream_t st, long n, double* A, long lda, double* W, long ldw, double* T, int* info);
 // W = L^-1 (lower, n x n, ld ldw; W must be zero above the diagonal on entry), T scratch of
 // gpx_trtri_scratch(n) doubles.
 long gpx_trtri_scratch(long n);
@@ -48,7 +51,8 @@ int gpx_logdiag_sum(hipStream_t st, long n, const double* A, long lda, double* o
 
 // ---- vecops.hip -----------------------------------------------------------------------------
 // y -= A x (A M x K, M-contiguous) ; y -= A^T x (y has K entries)
+// tri = 1: A is lower triangular (entries above the diagonal are skipped)
 int gpx_gemv_n(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
-               double beta, double* y);
+               double beta, double* y, int tri = 0);
 int gpx_gemv_t(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
-               double beta, double* y);
+               double beta, double* y, int tri = 0);

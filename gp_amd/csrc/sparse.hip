@@ -269,8 +269,15 @@ struct Sparse {
         hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, Inv, ldm);
         return GPX_OK;
     }
+    // Inv (full, symmetric) = Winv^T Winv
+    int gram(const double* Winv, double* Inv) {
+        int rc;
+        if ((rc = gpx_lauum(st, m, Winv, ldm, Inv, ldm))) return rc;
+        hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, Inv, ldm);
+        return GPX_OK;
+    }
     // inputs, Kuu (+jitter on its diagonal) factored into Lu, Kxu
-    int kernels(double kuu_jitter) {
+    int kernels(double kuu_jitter, bool fused_inverse = false) {
         int rc;
         if ((rc = gpx_scale_inputs(st, c->X.p, n, d, c->dpad, h.sc, c->Xt.p, c->ldx))) return rc;
         if ((rc = gpx_scale_inputs(st, c->U.p, m, d, c->dpad, h.sc, c->Ut.p, c->ldu))) return rc;
@@ -278,7 +285,12 @@ struct Sparse {
             return rc;
         HIP_TRY(hipMemcpyAsync(c->Lu.p, c->Kuu.p, (size_t)ldm * m * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemsetAsync(c->info, 0, 2 * sizeof(int), st));
-        if ((rc = gpx_potrf(st, m, c->Lu.p, ldm, c->Wd_u.p, c->info))) return rc;
+        if (fused_inverse) {
+            HIP_TRY(hipMemsetAsync(c->Winv_u.p, 0, (size_t)ldm * m * sizeof(double), st));
+            if ((rc = gpx_potrf_inv(st, m, c->Lu.p, ldm, c->Winv_u.p, ldm, c->T.p, c->info))) return rc;
+        } else if ((rc = gpx_potrf(st, m, c->Lu.p, ldm, c->Wd_u.p, c->info))) {
+            return rc;
+        }
         if ((rc = gpx_cov_build(st, c->Xt.p, c->ldx, n, c->Ut.p, c->ldu, m, c->dpad, h.sf2, c->Kxu.p, ldn, 0, 0.0)))
             return rc;
         return gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p);
@@ -317,12 +329,11 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     if (calc_grad) memset(grad, 0, sizeof(double) * nh);  // FITC.cpp:232 / VFE.cpp:194 on failure
 
     // ---- phase 1 ------------------------------------------------------------------------------
-    if ((rc = s.kernels(jitter))) return rc;
+    if ((rc = s.kernels(jitter, true))) return rc;  // Lu diag + Winv_u = Lu^-1
     HIP_TRY(hipMemsetAsync(redT, 0, 16 * sizeof(double), st));
     const double* Sop = fitc ? Ksc : c->Kxu.p;
     if (fitc) {
         // V = Kxu Lu^-T (FITC.cpp:213-215 via the factor: diag(Kxu Kuu^-1 Kux) = rowsum(V o V))
-        if ((rc = s.inverse(c->Lu.p, c->Wd_u.p, c->Winv_u.p, nullptr, true))) return rc;
         if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->Winv_u.p, ldm, 0.0, c->V.p, ldn, GEMM_KHI_N)))
             return rc;
         hipLaunchKernelGGL(fitc_gamma_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, c->V.p, ldn, c->Kxu.p, c->r.p, h.sn2,
@@ -344,17 +355,18 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     hipLaunchKernelGGL(mm_combine_lower_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, h.sn2, c->Kuu.p, ldm, 1.0, red, m,
                        0.0, c->Am.p, ldm);
     HIP_TRY(hipMemcpyAsync(c->LA.p, c->Am.p, (size_t)ldm * m * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if ((rc = gpx_potrf(st, m, c->LA.p, ldm, c->Wd_A.p, c->info + 1))) return rc;
-    HIP_TRY(hipMemcpyAsync(a_vec, redF, m * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if ((rc = gpx_trsv(st, m, c->LA.p, ldm, c->Wd_A.p, a_vec, 0))) return rc;
-    if ((rc = gpx_trsv(st, m, c->LA.p, ldm, c->Wd_A.p, a_vec, 1))) return rc;
+    HIP_TRY(hipMemsetAsync(c->Winv_A.p, 0, (size_t)ldm * m * sizeof(double), st));
+    if ((rc = gpx_potrf_inv(st, m, c->LA.p, ldm, c->Winv_A.p, ldm, c->T.p, c->info + 1))) return rc;
+    // a = A^-1 F = W_A^T (W_A F)
+    if ((rc = gpx_gemv_n(st, m, m, 1.0, c->Winv_A.p, ldm, redF, 0.0, c->vm[1].p, 1))) return rc;
+    if ((rc = gpx_gemv_t(st, m, m, 1.0, c->Winv_A.p, ldm, c->vm[1].p, 0.0, a_vec, 1))) return rc;
     if ((rc = gpx_logdiag_sum(st, m, c->Lu.p, ldm, c->scal.p + S_LDU))) return rc;
     if ((rc = gpx_logdiag_sum(st, m, c->LA.p, ldm, c->scal.p + S_LDA))) return rc;
     hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, st, m, redF, a_vec, c->scal.p + S_FA);
     if (!fitc) {
         // VFE needs Kuu^-1 for the trace term already in the NLL (VFE.cpp:181,188)
         hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, red, m);
-        if ((rc = s.inverse(c->Lu.p, c->Wd_u.p, c->Winv_u.p, c->Kuu_inv.p))) return rc;
+        if ((rc = s.gram(c->Winv_u.p, c->Kuu_inv.p))) return rc;
         hipLaunchKernelGGL(mm_inner_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, c->Kuu_inv.p, ldm, red, m, s.part());
         s.finish_partials(m * m, c->scal.p + S_TRKS, 1);
     }
@@ -382,7 +394,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     if (!calc_grad) return GPX_OK;
 
     // ---- phase 3 ------------------------------------------------------------------------------
-    if ((rc = s.inverse(c->LA.p, c->Wd_A.p, c->Winv_A.p, c->A_inv.p))) return rc;
+    if ((rc = s.gram(c->Winv_A.p, c->A_inv.p))) return rc;
     if ((rc = gpx_gemv_n(st, n, m, 1.0, c->Kxu.p, ldn, a_vec, 0.0, Ka))) return rc;  // Kxu a
     TraceArgs ta = {};
     ta.Xt1 = c->Xt.p; ta.ld1 = c->ldx; ta.p = n;
@@ -392,7 +404,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     ta.v = a_vec;
     HIP_TRY(hipMemsetAsync(redT, 0, (GPX_MAX_DIM + 32) * sizeof(double), st));
     if (fitc) {
-        if ((rc = s.inverse(c->Lu.p, c->Wd_u.p, c->Winv_u.p, c->Kuu_inv.p))) return rc;
+        if ((rc = s.gram(c->Winv_u.p, c->Kuu_inv.p))) return rc;
         // C = Gamma^-1 Kxu A^-1 (FITC.cpp:262) and B = Kxu Kuu^-1 = V Lu^-1 (FITC.cpp:214)
         double* Cm = c->Tm.p;
         if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, Ksc, ldn, c->A_inv.p, ldm, 0.0, Cm, ldn, 0))) return rc;

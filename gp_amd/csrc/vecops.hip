@@ -7,21 +7,27 @@ namespace {
 // y[i] = beta*y[i] + alpha * sum_k A[i + k*lda] x[k]; 64 rows per workgroup, 4 waves split K
 __global__ __launch_bounds__(256) void gemv_n_kernel(long M, long K, double alpha, const double* __restrict__ A,
                                                      long lda, const double* __restrict__ x, double beta,
-                                                     double* __restrict__ y) {
+                                                     double* __restrict__ y, int tri) {
     __shared__ double red[4][64];
+    // lower triangular A: full columns are those left of this row block; the diagonal block is masked
+    const long Kf = tri ? min(K, (long)blockIdx.x * 64) : K;
+    if (tri) K = min(K, ((long)blockIdx.x + 1) * 64);
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * 64 + l;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (i < M) {
         const double* a = A + i;
         long k = w;
-        for (; k + 12 < K; k += 16) {
+        for (; k + 12 < Kf; k += 16) {
             s0 = fma(a[k * lda], x[k], s0);
             s1 = fma(a[(k + 4) * lda], x[k + 4], s1);
             s2 = fma(a[(k + 8) * lda], x[k + 8], s2);
             s3 = fma(a[(k + 12) * lda], x[k + 12], s3);
         }
-        for (; k < K; k += 4) s0 = fma(a[k * lda], x[k], s0);
+        for (; k < Kf; k += 4) s0 = fma(a[k * lda], x[k], s0);
+        if (tri)
+            for (; k < K; k += 4)
+                if (k <= i) s0 = fma(a[k * lda], x[k], s0);
     }
     red[w][l] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -34,13 +40,13 @@ __global__ __launch_bounds__(256) void gemv_n_kernel(long M, long K, double alph
 // y[j] = beta*y[j] + alpha * sum_i A[i + j*lda] x[i]; one wave per column
 __global__ __launch_bounds__(256) void gemv_t_kernel(long M, long K, double alpha, const double* __restrict__ A,
                                                      long lda, const double* __restrict__ x, double beta,
-                                                     double* __restrict__ y) {
+                                                     double* __restrict__ y, int tri) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long j = (long)blockIdx.x * 4 + w;
     if (j >= K) return;
     const double* a = A + j * lda;
     double s0 = 0.0, s1 = 0.0;
-    long i = l;
+    long i = l + (tri ? j : 0);  // lower triangular: rows >= column
     for (; i + 64 < M; i += 128) {
         s0 = fma(a[i], x[i], s0);
         s1 = fma(a[i + 64], x[i + 64], s1);
@@ -54,17 +60,17 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(long M, long K, double alph
 }  // namespace
 
 int gpx_gemv_n(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
-               double beta, double* y) {
+               double beta, double* y, int tri) {
     if (M <= 0) return GPX_OK;
     hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, st, M, K, alpha, A, lda, x,
-                       beta, y);
+                       beta, y, tri);
     return GPX_OK;
 }
 
 int gpx_gemv_t(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
-               double beta, double* y) {
+               double beta, double* y, int tri) {
     if (K <= 0) return GPX_OK;
     hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, st, M, K, alpha, A, lda, x, beta,
-                       y);
+                       y, tri);
     return GPX_OK;
 }
