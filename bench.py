@@ -56,7 +56,7 @@ class Dist:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.torch = None
         self.dist = None
-        if self.world > 1:
+        if self.world > 1 or os.environ.get("GPX_BENCH_FORCE_DIST") == "1":
             import torch
             import torch.distributed as dist
             torch.cuda.set_device(self.local_rank)
@@ -125,7 +125,7 @@ def run_sparse(D, lib, synth, model, n, m, d, steps, warmup, cfg_index):
     ctx = lib.Context(D.local_rank)
     ctx.set_data(X, y)
     ctx.set_inducing(U)
-    if D.world > 1:
+    if D.dist is not None:
         ctx.set_allreduce(D.allreduce_ptr)
     M = lib.MODEL_FITC if model == "fitc" else lib.MODEL_VFE
     jitter = 1e-8   # (0.1 * noise_lb)^2 with the default noise_lb = 1e-3 (FITC.cpp:30, GP.cpp:28)

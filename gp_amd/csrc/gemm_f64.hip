@@ -301,15 +301,15 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
 
 // bare MFMA loop: what the matrix pipe delivers with operands in registers
 __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
-    v4d acc[8];
-    for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    v4d acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
     double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
     }
     double s = 0;
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     out[(long)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
@@ -348,7 +348,7 @@ int gpx_gemm_prof_end(double* total_ms, double* total_flops, long* launches, dou
 }
 
 int gpx_mfma_peak(double* tflops) {
-    const int blocks = 256 * 2, iters = 40000;
+    const int blocks = 256 * 8, iters = 8192;  // 8 waves per SIMD, 4 independent accumulators each
     double* out = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out), (size_t)blocks * 256 * 8));
     hipEvent_t e0, e1;
@@ -361,7 +361,7 @@ int gpx_mfma_peak(double* tflops) {
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    *tflops = (double)blocks * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
+    *tflops = (double)blocks * 4 * iters * 4 * 2048.0 / (ms * 1e-3) / 1e12;
     (void)hipFree(out);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

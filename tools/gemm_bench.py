@@ -14,8 +14,9 @@ from gp_amd import lib  # noqa: E402
 def bench(M, N, K, a_kc, b_kc, flags=0, reps=3, name=""):
     rng = np.random.default_rng(0)
     ld = max(M, N, K) + 16
-    A = lib.DeviceBuffer.from_numpy(rng.uniform(-1, 1, ld * max(M, K)))
-    B = lib.DeviceBuffer.from_numpy(rng.uniform(-1, 1, ld * max(N, K)))
+    base = rng.uniform(-1, 1, 1 << 20)
+    A = lib.DeviceBuffer.from_numpy(np.resize(base, ld * max(M, K)))
+    B = lib.DeviceBuffer.from_numpy(np.resize(base[::-1], ld * max(N, K)))
     Cd = lib.DeviceBuffer(ld * N)
     Cd.zero()
 
@@ -36,6 +37,9 @@ def bench(M, N, K, a_kc, b_kc, flags=0, reps=3, name=""):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+    if len(sys.argv) > 2:   # single case for PMC passes
+        bench(n, n, n, 0, 0, name="NT", reps=2)
+        sys.exit(0)
     bench(n, n, n, 0, 0, name="NT (potrf trsm/syrk form)")
     bench(n, n, n, 0, 0, lib.GEMM_LOWER, name="NT lower (syrk)")
     bench(n, n, n, 0, 1, name="NN (trtri)")
