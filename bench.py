@@ -87,6 +87,20 @@ class Dist:
         return float(t.item())
 
 
+def pmc_traffic(n):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE doubled as the gfx950 correction prescribes, + WRITE_SIZE; tools/pmc_bench.sh)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc", f"exact_n{n}_traffic.json")
+    if not os.path.exists(path):
+        return None
+    tot, cnt = 0.0, 0
+    for k, v in json.load(open(path)).items():
+        if k.startswith("gemm_kernel<4, 4"):
+            tot += (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"]) * v["launches"]
+            cnt += v["launches"]
+    return tot / cnt / 1e9 if cnt else None
+
+
 def timed(D, lib, fn, steps, warmup, prof_min_flops):
     out = None
     for _ in range(warmup):
@@ -170,7 +184,8 @@ def main():
                        "parallelism": "replicas" if D.world > 1 else "single"},
             "nll": nll, "algorithmic_tflops_per_gpu": alg_tf, "frac_fp64_peak_whole_eval": alg_tf / FP64_MFMA_PEAK_TFLOPS,
             "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gemm_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": gemm_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(n),
+                         "traffic_unit": "GB per launch (L2-miss bytes incl. Infinity-Cache hits; separate --pmc passes, profiles/r01_pmc)",
                          "kernel": "gemm_kernel<4,4,*,*> (fp64 MFMA GEMM/SYRK/TRMM tiles; all launches >= 1 GFLOP)",
                          "launches_per_eval": prof["launches"], "kernel_ms_per_eval": prof["gemm_ms"],
                          "algorithmic_flops_per_eval": prof["gemm_flops"],
