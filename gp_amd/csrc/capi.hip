@@ -33,7 +33,7 @@ int gpx_ctx_destroy(gpx_ctx* c) {
                       &c->nalpha, &c->scal, &c->trace_ws, &c->Kxu, &c->V, &c->Bm, &c->Cm, &c->Kuu, &c->Lu,
                       &c->Am, &c->LA, &c->Winv_u, &c->Winv_A, &c->Kuu_inv, &c->A_inv, &c->Wuu, &c->Tm,
                       &c->Wd_u, &c->Wd_A, &c->red, &c->pred_K, &c->pred_xs, &c->pred_xst, &c->pred_out,
-                      &c->pred_tmp, &c->pLu, &c->pLA, &c->pWd_u, &c->pWd_A, &c->palpha, &c->pUt};
+                      &c->pred_tmp, &c->pred_K2, &c->pred_g, &c->pLu, &c->pLA, &c->pWd_u, &c->pWd_A, &c->palpha, &c->pUt};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : c->vn) b.release();
     for (auto& b : c->vm) b.release();
@@ -102,14 +102,19 @@ int gpx_prepare(gpx_ctx* c, int model, int cov, double* hyp, double* jitter) {
     return GPX_ERR_ARG;
 }
 
-int gpx_predict(gpx_ctx* c, const double* Xs, int64_t t, double* mu, double* s2) {
+int gpx_predict_with_grad(gpx_ctx* c, const double* Xs, int64_t t, double* mu, double* s2, double* gmu, double* gs2) {
     if (!c || !Xs || t < 0) return GPX_ERR_ARG;
     if (t == 0) return GPX_OK;
     HIP_TRY(hipSetDevice(c->dev));
-    if (c->prepared_model == GPX_MODEL_EXACT) return gpx_exact_predict(c, Xs, t, mu, s2);
+    if (c->prepared_model == GPX_MODEL_EXACT) return gpx_exact_predict(c, Xs, t, mu, s2, gmu, gs2);
+    if (c->prepared_model == GPX_MODEL_VFE && gs2) return GPX_ERR_UNSUPPORTED;  // VFE.cpp:125-131 has no s2 gradient
     if (c->prepared_model == GPX_MODEL_FITC || c->prepared_model == GPX_MODEL_VFE)
-        return gpx_sparse_predict(c, Xs, t, mu, s2);
+        return gpx_sparse_predict(c, Xs, t, mu, s2, gmu, gs2);
     return GPX_ERR_STATE;
+}
+
+int gpx_predict(gpx_ctx* c, const double* Xs, int64_t t, double* mu, double* s2) {
+    return gpx_predict_with_grad(c, Xs, t, mu, s2, nullptr, nullptr);
 }
 
 int gpx_cov_k(int cov, int64_t d, const double* hyp, const double* x1, int64_t p, const double* x2, int64_t q,

@@ -51,7 +51,7 @@ struct gpx_ctx {
     int prepared_model = -1, prepared_cov = 0;
     std::vector<double> prepared_hyp;
     double prepared_jitter = 0;
-    DevBuf pred_K, pred_xs, pred_xst, pred_out, pred_tmp;
+    DevBuf pred_K, pred_K2, pred_xs, pred_xst, pred_out, pred_tmp, pred_g;
     DevBuf pLu, pLA, pWd_u, pWd_A, palpha, pUt;  // sparse _setK state, private copies (objective calls keep it valid)
 };
 
@@ -80,13 +80,19 @@ inline int parse_hyp(int cov, int d, const double* hyp, HypView& h) {
 // exact.hip
 int gpx_exact_nll_grad(gpx_ctx* c, int cov, const double* hyp, int calc_grad, double* nll, double* grad);
 int gpx_exact_prepare(gpx_ctx* c, int cov, double* hyp);
-int gpx_exact_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double* s2);
+int gpx_exact_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double* s2, double* gmu, double* gs2);
 // sparse.hip
 int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int calc_grad, double jitter,
                         double* nll, double* grad);
 int gpx_sparse_prepare(gpx_ctx* c, int model, int cov, const double* hyp, double* jitter);
-int gpx_sparse_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double* s2);
+int gpx_sparse_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double* s2, double* gmu, double* gs2);
 // small shared kernels (exact.hip)
 int gpx_vec_shift(hipStream_t st, long n, const double* y, double shift, double scale, double* out);
 int gpx_reduce3(hipStream_t st, long n, const double* a, const double* b, double* out3);
 int gpx_colsumsq(hipStream_t st, long n, long t, const double* V, long ldv, double* out);
+// Input gradients of the predictive mean / variance (GP.cpp:284-296; CovSEard.cpp:28-40):
+//   gmu[i,j] = sum_b dk_ib alpha_b,  gs2[i,j] = -2 sum_b dk_ib (Q1[b,j] - c2*Q2[b,j]),
+//   dk_ib = Kstar[b,j] * (x_ib - xs_ij) / l_i^2; Xt/Xst are the scaled dimension-major inputs.
+int gpx_predict_grad(hipStream_t st, long p, long t, int d, const double* Xt, long ldx, const double* Xst, long ldt,
+                     const ScaleArgs& sc, const double* Kstar, long ldk, const double* alpha, const double* Q1,
+                     const double* Q2, long ldq, double c2, double* gmu, double* gs2);

@@ -59,6 +59,46 @@ __global__ void predict_finish_kernel(long t, const double* __restrict__ ksa, co
     if (s2) s2[j] = fmax(sf2 - vsq[j], 0.0) + sn2;  // GP.cpp:283
 }
 
+// one workgroup per test point j; for every dimension a block reduction over the p kernel points
+__global__ __launch_bounds__(256) void predict_grad_kernel(long p, int d, const double* __restrict__ Xt, long ldx,
+                                                           const double* __restrict__ Xst, long ldt, ScaleArgs sc,
+                                                           const double* __restrict__ Ks, long ldk,
+                                                           const double* __restrict__ alpha, const double* __restrict__ Q1,
+                                                           const double* __restrict__ Q2, long ldq, double c2,
+                                                           double* __restrict__ gmu, double* __restrict__ gs2) {
+    __shared__ double red[2][4];
+    const long j = blockIdx.x;
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = 0; i < d; ++i) {
+        const double il = sc.divide ? 1.0 / sc.s[i] : sc.s[i];  // 1 / l_i
+        const double xs = Xst[(long)i * ldt + j];
+        double s1 = 0.0, s2 = 0.0;
+        for (long b = threadIdx.x; b < p; b += 256) {
+            const double dk = Ks[b + j * ldk] * ((Xt[(long)i * ldx + b] - xs) * il);
+            s1 = fma(dk, alpha[b], s1);
+            if (gs2) {
+                double q = Q1[b + j * ldq];
+                if (Q2) q -= c2 * Q2[b + j * ldq];
+                s2 = fma(dk, q, s2);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+        }
+        __syncthreads();
+        if (l == 0) {
+            red[0][w] = s1;
+            red[1][w] = s2;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (gmu) gmu[i + j * d] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            if (gs2) gs2[i + j * d] = 0.0 - 2 * ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));  // diag_dk_dx1 == 0
+        }
+    }
+}
+
 const double INF = std::numeric_limits<double>::infinity();
 
 // K + sn2 I -> A (lower), factor in place, alpha = (K + sn2 I)^-1 (y - mean).  Leaves the device
@@ -100,6 +140,15 @@ int gpx_reduce3(hipStream_t st, long n, const double* a, const double* b, double
 int gpx_colsumsq(hipStream_t st, long n, long t, const double* V, long ldv, double* out) {
     if (t <= 0) return GPX_OK;
     hipLaunchKernelGGL(colsumsq_kernel, dim3((unsigned)((t + 3) / 4)), dim3(256), 0, st, n, t, V, ldv, out);
+    return GPX_OK;
+}
+
+int gpx_predict_grad(hipStream_t st, long p, long t, int d, const double* Xt, long ldx, const double* Xst, long ldt,
+                     const ScaleArgs& sc, const double* Kstar, long ldk, const double* alpha, const double* Q1,
+                     const double* Q2, long ldq, double c2, double* gmu, double* gs2) {
+    if (t <= 0) return GPX_OK;
+    hipLaunchKernelGGL(predict_grad_kernel, dim3((unsigned)t), dim3(256), 0, st, p, d, Xt, ldx, Xst, ldt, sc, Kstar, ldk,
+                       alpha, Q1, Q2, ldq, c2, gmu, gs2);
     return GPX_OK;
 }
 
@@ -213,18 +262,20 @@ int gpx_exact_prepare(gpx_ctx* c, int cov, double* hyp) {
     return GPX_ERR_STATE;
 }
 
-int gpx_exact_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double* s2) {
+int gpx_exact_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double* s2, double* gmu, double* gs2) {
     if (c->prepared_model != GPX_MODEL_EXACT) return GPX_ERR_STATE;
     const long n = c->n;
     const int d = c->d;
     HypView h;
     int rc = parse_hyp(c->prepared_cov, d, c->prepared_hyp.data(), h);
     if (rc) return rc;
-    const long chunk = 4096;
+    const bool grad = gmu || gs2;
+    const long chunk = grad ? 512 : 4096;
     const long ldk = gpx_ld(n), ldt = gpx_ld(chunk);
     if ((rc = c->pred_K.ensure(ldk * chunk)) || (rc = c->pred_xs.ensure((long)d * chunk)) ||
         (rc = c->pred_xst.ensure((long)c->dpad * ldt)) || (rc = c->pred_out.ensure(4 * chunk)))
         return rc;
+    if (grad && ((rc = c->pred_K2.ensure(ldk * chunk)) || (rc = c->pred_g.ensure(2L * d * chunk)))) return rc;
     double* d_ksa = c->pred_out.p;
     double* d_vsq = c->pred_out.p + chunk;
     double* d_mu = c->pred_out.p + 2 * chunk;
@@ -237,13 +288,27 @@ int gpx_exact_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double* 
         if ((rc = gpx_cov_build(c->st, c->Xt.p, c->ldx, n, c->pred_xst.p, ldt, tc, c->dpad, h.sf2, c->pred_K.p, ldk, 0, 0.0)))
             return rc;
         if ((rc = gpx_gemv_t(c->st, n, tc, 1.0, c->pred_K.p, ldk, c->alpha.p, 0.0, d_ksa))) return rc;
-        if (s2) {
+        // the solves run on a copy when the kernel values are still needed for the gradients
+        double* V = grad ? c->pred_K2.p : c->pred_K.p;
+        if (grad) HIP_TRY(hipMemcpyAsync(V, c->pred_K.p, (size_t)ldk * tc * sizeof(double), hipMemcpyDeviceToDevice, c->st));
+        if (s2 || gs2) {
             // k* K^-1 k*^T = |L^-1 k*^T|^2 per column (GP.cpp:281-283 uses the two-sided solve)
-            if ((rc = gpx_trsm_left(c->st, n, tc, c->A.p, c->lda, c->Wd.p, c->pred_K.p, ldk, 0))) return rc;
-            if ((rc = gpx_colsumsq(c->st, n, tc, c->pred_K.p, ldk, d_vsq))) return rc;
+            if ((rc = gpx_trsm_left(c->st, n, tc, c->A.p, c->lda, c->Wd.p, V, ldk, 0))) return rc;
+            if ((rc = gpx_colsumsq(c->st, n, tc, V, ldk, d_vsq))) return rc;
         }
         hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((tc + 255) / 256)), dim3(256), 0, c->st, tc, d_ksa,
                            d_vsq, h.mean, h.sf2, h.sn2, mu ? d_mu : nullptr, s2 ? d_s2 : nullptr);
+        if (grad) {
+            // kks = K^-1 k*^T (GP.cpp:281), then gy = dk * invKys, gs2 = -2 dk * kks (GP.cpp:292-294)
+            if (gs2 && (rc = gpx_trsm_left(c->st, n, tc, c->A.p, c->lda, c->Wd.p, V, ldk, 1))) return rc;
+            double* d_gmu = c->pred_g.p;
+            double* d_gs2 = c->pred_g.p + (long)d * chunk;
+            if ((rc = gpx_predict_grad(c->st, n, tc, d, c->Xt.p, c->ldx, c->pred_xst.p, ldt, h.sc, c->pred_K.p, ldk, c->alpha.p,
+                                       V, nullptr, ldk, 0.0, gmu ? d_gmu : nullptr, gs2 ? d_gs2 : nullptr)))
+                return rc;
+            if (gmu) HIP_TRY(hipMemcpyAsync(gmu + t0 * d, d_gmu, (size_t)tc * d * sizeof(double), hipMemcpyDeviceToHost, c->st));
+            if (gs2) HIP_TRY(hipMemcpyAsync(gs2 + t0 * d, d_gs2, (size_t)tc * d * sizeof(double), hipMemcpyDeviceToHost, c->st));
+        }
         if (mu) HIP_TRY(hipMemcpyAsync(mu + t0, d_mu, tc * sizeof(double), hipMemcpyDeviceToHost, c->st));
         if (s2) HIP_TRY(hipMemcpyAsync(s2 + t0, d_s2, tc * sizeof(double), hipMemcpyDeviceToHost, c->st));
         HIP_TRY(hipStreamSynchronize(c->st));

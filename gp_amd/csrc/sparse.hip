@@ -582,7 +582,7 @@ int gpx_sparse_prepare(gpx_ctx* c, int model, int cov, const double* hyp, double
     return GPX_ERR_STATE;
 }
 
-int gpx_sparse_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double* s2) {
+int gpx_sparse_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double* s2, double* gmu, double* gs2) {
     const long m = c->m;
     const int d = c->d;
     const bool fitc = c->prepared_model == GPX_MODEL_FITC;
@@ -590,13 +590,16 @@ int gpx_sparse_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double*
     int rc = parse_hyp(c->prepared_cov, d, c->prepared_hyp.data(), h);
     if (rc) return rc;
     hipStream_t st = c->st;
-    const long chunk = 16384;
+    const bool grad = gmu || gs2;
+    const long chunk = grad ? 2048 : 16384;
     const long ldm = gpx_ld(m), ldt = gpx_ld(chunk);
-    if ((rc = c->pred_K.ensure(2 * ldm * chunk)) || (rc = c->pred_xs.ensure((long)d * chunk)) ||
+    if ((rc = c->pred_K.ensure(3 * ldm * chunk)) || (rc = c->pred_xs.ensure((long)d * chunk)) ||
         (rc = c->pred_xst.ensure((long)c->dpad * ldt)) || (rc = c->pred_out.ensure(5 * chunk)))
         return rc;
-    double* K1 = c->pred_K.p;
-    double* K2 = c->pred_K.p + ldm * chunk;
+    if (grad && (rc = c->pred_g.ensure(2L * d * chunk))) return rc;
+    double* K0 = c->pred_K.p;               // K_star^T, kept for the gradients
+    double* K1 = c->pred_K.p + ldm * chunk;
+    double* K2 = c->pred_K.p + 2 * ldm * chunk;
     double* d_ksa = c->pred_out.p;
     double* d_vu = d_ksa + chunk;
     double* d_vA = d_vu + chunk;
@@ -607,11 +610,12 @@ int gpx_sparse_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double*
         HIP_TRY(hipMemcpyAsync(c->pred_xs.p, Xs + t0 * d, (size_t)tc * d * sizeof(double), hipMemcpyHostToDevice, st));
         if ((rc = gpx_scale_inputs(st, c->pred_xs.p, tc, d, c->dpad, h.sc, c->pred_xst.p, ldt))) return rc;
         // K_star^T = k(U, Xs): m x tc   (FITC.cpp:114, VFE.cpp:116)
-        if ((rc = gpx_cov_build(st, c->pUt.p, c->ldu, m, c->pred_xst.p, ldt, tc, c->dpad, h.sf2, K1, ldm, 0, 0.0))) return rc;
-        if ((rc = gpx_gemv_t(st, m, tc, 1.0, K1, ldm, c->palpha.p, 0.0, d_ksa))) return rc;
-        if (s2) {
+        if ((rc = gpx_cov_build(st, c->pUt.p, c->ldu, m, c->pred_xst.p, ldt, tc, c->dpad, h.sf2, K0, ldm, 0, 0.0))) return rc;
+        if ((rc = gpx_gemv_t(st, m, tc, 1.0, K0, ldm, c->palpha.p, 0.0, d_ksa))) return rc;
+        if (s2 || gs2) {
             // k*(Kuu^-1 - c A^-1)k*^T = |Lu^-1 k*|^2 - c |LA^-1 k*|^2   (FITC.cpp:115-117, VFE.cpp:129-130)
-            HIP_TRY(hipMemcpyAsync(K2, K1, (size_t)ldm * tc * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(K1, K0, (size_t)ldm * tc * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(K2, K0, (size_t)ldm * tc * sizeof(double), hipMemcpyDeviceToDevice, st));
             if ((rc = gpx_trsm_left(st, m, tc, c->pLu.p, ldm, c->pWd_u.p, K1, ldm, 0))) return rc;
             if ((rc = gpx_trsm_left(st, m, tc, c->pLA.p, ldm, c->pWd_A.p, K2, ldm, 0))) return rc;
             if ((rc = gpx_colsumsq(st, m, tc, K1, ldm, d_vu))) return rc;
@@ -619,6 +623,19 @@ int gpx_sparse_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double*
         }
         hipLaunchKernelGGL(predict_sparse_finish_kernel, dim3(nblk(tc)), dim3(256), 0, st, tc, d_ksa, d_vu, d_vA, h.mean,
                            h.sf2, h.sn2, fitc ? 1 : 0, mu ? d_mu : nullptr, s2 ? d_s2 : nullptr);
+        if (grad) {
+            if (gs2) {  // KinvK = Kuu^-1 k* - sn2 A^-1 k*   (FITC.cpp:115, 127)
+                if ((rc = gpx_trsm_left(st, m, tc, c->pLu.p, ldm, c->pWd_u.p, K1, ldm, 1))) return rc;
+                if ((rc = gpx_trsm_left(st, m, tc, c->pLA.p, ldm, c->pWd_A.p, K2, ldm, 1))) return rc;
+            }
+            double* d_gmu = c->pred_g.p;
+            double* d_gs2 = c->pred_g.p + (long)d * chunk;
+            if ((rc = gpx_predict_grad(st, m, tc, d, c->pUt.p, c->ldu, c->pred_xst.p, ldt, h.sc, K0, ldm, c->palpha.p, K1, K2, ldm,
+                                       fitc ? h.sn2 : 1.0, gmu ? d_gmu : nullptr, gs2 ? d_gs2 : nullptr)))
+                return rc;
+            if (gmu) HIP_TRY(hipMemcpyAsync(gmu + t0 * d, d_gmu, (size_t)tc * d * sizeof(double), hipMemcpyDeviceToHost, st));
+            if (gs2) HIP_TRY(hipMemcpyAsync(gs2 + t0 * d, d_gs2, (size_t)tc * d * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
         if (mu) HIP_TRY(hipMemcpyAsync(mu + t0, d_mu, tc * sizeof(double), hipMemcpyDeviceToHost, st));
         if (s2) HIP_TRY(hipMemcpyAsync(s2 + t0, d_s2, tc * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

@@ -236,7 +236,66 @@ void GP::_predict(const MatrixXd& x, VectorXd* y, VectorXd* s2) const {
     if (s2) *s2 = VectorXd(x.cols());
     must(gpx_predict(_ctx, x.data(), (int64_t)x.cols(), y ? y->data() : nullptr, s2 ? s2->data() : nullptr), "predict");
 }
+// GP.cpp:284-296, 305-313, 324-333 / FITC.cpp:118-129 / VFE.cpp:118-123, all test points in one call
+void GP::_predict_g(const MatrixXd& x, VectorXd* y, VectorXd* s2, MatrixXd* gy, MatrixXd* gs2) const {
+    assert(_trained);
+    if (x.rows() != _dim) throw std::invalid_argument("predict: dimension");
+    if (gs2 && _model() == GPX_MODEL_VFE)
+        throw std::logic_error("VFE has no predictive-variance input gradient (VFE.cpp:109-112, 125-131)");
+    VectorXd yy(x.cols()), ss(x.cols());
+    if (gy) *gy = MatrixXd(_dim, x.cols());
+    if (gs2) *gs2 = MatrixXd(_dim, x.cols());
+    must(gpx_predict_with_grad(_ctx, x.data(), (int64_t)x.cols(), yy.data(), ss.data(), gy ? gy->data() : nullptr,
+                               gs2 ? gs2->data() : nullptr),
+         "predict_with_grad");
+    if (y) *y = yy;
+    if (s2) *s2 = ss;
+}
 static MatrixXd as_col(const VectorXd& v) { return MatrixXd(v); }
+static VectorXd col0(const MatrixXd& m) {
+    VectorXd v(m.rows());
+    for (long i = 0; i < (long)m.rows(); ++i) v[i] = m(i, 0);
+    return v;
+}
+double GP::predict_y_with_grad(const VectorXd& xs, VectorXd& g) const {
+    VectorXd y;
+    MatrixXd gg;
+    _predict_g(as_col(xs), &y, nullptr, &gg, nullptr);
+    g = col0(gg);
+    return y[0];
+}
+double GP::predict_s2_with_grad(const VectorXd& xs, VectorXd& g) const {
+    VectorXd s;
+    MatrixXd gg;
+    _predict_g(as_col(xs), nullptr, &s, nullptr, &gg);
+    g = col0(gg);
+    return s[0];
+}
+std::pair<double, VectorXd> GP::predict_y_with_grad(const VectorXd& xs) const {
+    VectorXd g;
+    const double y = predict_y_with_grad(xs, g);
+    return {y, g};
+}
+std::pair<double, VectorXd> GP::predict_s2_with_grad(const VectorXd& xs) const {
+    VectorXd g;
+    const double s = predict_s2_with_grad(xs, g);
+    return {s, g};
+}
+void GP::predict_with_grad(const VectorXd& xs, double& y, double& s2, VectorXd& gy, VectorXd& gs2) const {
+    VectorXd yy, ss;
+    MatrixXd g1, g2;
+    _predict_g(as_col(xs), &yy, &ss, &g1, &g2);
+    y = yy[0];
+    s2 = ss[0];
+    gy = col0(g1);
+    gs2 = col0(g2);
+}
+std::tuple<double, double, VectorXd, VectorXd> GP::predict_with_grad(const VectorXd& xs) const {
+    double y, s2;
+    VectorXd gy, gs2;
+    predict_with_grad(xs, y, s2, gy, gs2);
+    return std::tuple<double, double, VectorXd, VectorXd>(y, s2, gy, gs2);
+}
 double GP::predict_y(const VectorXd& xs) const { VectorXd y; _predict(as_col(xs), &y, nullptr); return y[0]; }
 double GP::predict_s2(const VectorXd& xs) const { VectorXd s; _predict(as_col(xs), nullptr, &s); return s[0]; }
 void GP::predict(const VectorXd& xs, double& y, double& s2) const {

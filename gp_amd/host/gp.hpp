@@ -9,7 +9,8 @@
 //  * train() uses the built-in bounded L-BFGS (optimizer.hpp) instead of NLopt LD_SLSQP, and
 //    select_init_hyp() (MVMO, an un-vendored submodule of the reference) falls back to a
 //    deterministic scan over the bounds' interior.  Same budgets (160/130/150 evaluations).
-//  * predict*_with_grad (input gradients) are not provided yet.
+//  * VFE::predict_with_grad / predict_s2_with_grad throw std::logic_error where the reference
+//    has assert(not need_g) / leaves the gradient unset (VFE.cpp:109-112, 125-131).
 #pragma once
 #include <string>
 #include <tuple>
@@ -57,6 +58,8 @@ protected:
     double _calcNegLogProb(const VectorXd& hyp, VectorXd&) const;
     virtual double _calcNegLogProb(const VectorXd& hyp, VectorXd& g, bool calc_grad) const;
     virtual void _predict(const MatrixXd& x, VectorXd* y, VectorXd* s2) const;
+    // with input gradients (need_g = true in GP.h:62-64): gy / gs2 are dim x num_test
+    virtual void _predict_g(const MatrixXd& x, VectorXd* y, VectorXd* s2, MatrixXd* gy, MatrixXd* gs2) const;
     void _set_hyp_range();
     VectorXd vec2hyp(const std::vector<double>& vx) const;
     std::vector<double> hyp2vec(const VectorXd& vx) const;
@@ -95,8 +98,14 @@ public:
 
     double predict_y(const VectorXd& xs) const;
     double predict_s2(const VectorXd& xs) const;
+    double predict_y_with_grad(const VectorXd& xs, VectorXd& g) const;
+    double predict_s2_with_grad(const VectorXd& xs, VectorXd& g) const;
+    std::pair<double, VectorXd> predict_y_with_grad(const VectorXd& xs) const;
+    std::pair<double, VectorXd> predict_s2_with_grad(const VectorXd& xs) const;
     void predict(const VectorXd& xs, double& y, double& s2) const;
+    void predict_with_grad(const VectorXd& xs, double& y, double& s2, VectorXd& gy, VectorXd& gs2) const;
     std::tuple<double, double> predict(const VectorXd& xs) const;
+    std::tuple<double, double, VectorXd, VectorXd> predict_with_grad(const VectorXd& xs) const;
     VectorXd batch_predict_y(const MatrixXd& xs) const;
     VectorXd batch_predict_s2(const MatrixXd& xs) const;
     void batch_predict(const MatrixXd& xs, VectorXd& y, VectorXd& s2) const;

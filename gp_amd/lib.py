@@ -126,6 +126,7 @@ lib.gpx_set_allreduce.argtypes = [_vp, ALLREDUCE_FN, _vp]
 lib.gpx_nll_grad.argtypes = [_vp, _i, _i, _vp, _i, _d, C.POINTER(_d), _vp]
 lib.gpx_prepare.argtypes = [_vp, _i, _i, _vp, C.POINTER(_d)]
 lib.gpx_predict.argtypes = [_vp, _vp, _i64, _vp, _vp]
+lib.gpx_predict_with_grad.argtypes = [_vp, _vp, _i64, _vp, _vp, _vp, _vp]
 lib.gpx_cov_k.argtypes = [_i, _i64, _vp, _vp, _i64, _vp, _i64, _vp]
 lib.gpx_chol_solve.argtypes = [_i64, _vp, C.POINTER(_i), C.POINTER(_d), _vp, _i64, _vp]
 
@@ -195,6 +196,18 @@ class Context:
         check(lib.gpx_predict(self._h, Xs.ctypes.data, t, mu.ctypes.data if want_mu else None,
                               s2.ctypes.data if want_s2 else None), "predict")
         return mu, s2
+
+    def predict_with_grad(self, Xs, want_gs2=True):
+        """mu, s2 and their gradients w.r.t. the test inputs, each gradient (t, d) with one test
+        point per row (GP.cpp:284-296, 305-313, 324-333; FITC.cpp:118-129; VFE.cpp:118-123)."""
+        Xs = _c(Xs)
+        t = Xs.shape[0]
+        mu, s2 = np.empty(t), np.empty(t)
+        gmu = np.empty((t, self.d))
+        gs2 = np.empty((t, self.d)) if want_gs2 else None
+        check(lib.gpx_predict_with_grad(self._h, Xs.ctypes.data, t, mu.ctypes.data, s2.ctypes.data, gmu.ctypes.data,
+                                        gs2.ctypes.data if want_gs2 else None), "predict_with_grad")
+        return mu, s2, gmu, gs2
 
     def close(self):
         if self._h:

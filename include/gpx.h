@@ -80,6 +80,11 @@ int gpx_prepare(gpx_ctx* ctx, int model, int cov, double* hyp, double* jitter);
 /* GP::_predict / _predict_y / _predict_s2 (GP.cpp:273-334), FITC (FITC.cpp:109-164), VFE
  * (VFE.cpp:113-131) without input gradients: HOST Xs (d x t); mu and/or s2 may be NULL. */
 int gpx_predict(gpx_ctx* ctx, const double* Xs, int64_t t, double* mu, double* s2);
+/* The need_g = true branches of the same functions (GP.cpp:284-296, 305-313, 324-333;
+ * FITC.cpp:118-129; VFE.cpp:118-123) for t points at once: gmu, gs2 are d x t column-major
+ * (d mean / d x*, d s2 / d x*), each nullable.  VFE has no variance gradient (returns 4). */
+int gpx_predict_with_grad(gpx_ctx* ctx, const double* Xs, int64_t t, double* mu, double* s2, double* gmu,
+                          double* gs2);
 
 /* Cov::k (Cov/Cov.h:14; CovSEard.cpp:7-11, CovSEiso.cpp:6-11) on HOST buffers: x1 d x p, x2 d x q,
  * K p x q column-major.  hyp holds at least the kernel hypers. */

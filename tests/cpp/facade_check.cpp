@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <stdexcept>
 #include "../../gp_amd/host/gp.hpp"
 using namespace gpx;
 
@@ -32,6 +33,22 @@ static void run(const char* tag, M& gp, const VectorXd& init, const MatrixXd& te
     double y1, s1;
     gp.predict(test_x.col(0), y1, s1);
     std::snprintf(key, sizeof key, "%s_single", tag); std::printf("%s %.17g %.17g\n", key, y1, s1);
+    // input gradients at the first test point (GP.h:106-115); VFE has the mean gradient only
+    const VectorXd x0 = test_x.col(0);
+    VectorXd gy;
+    const double yg = gp.predict_y_with_grad(x0, gy);
+    std::snprintf(key, sizeof key, "%s_gy", tag); pv(key, gy);
+    std::snprintf(key, sizeof key, "%s_yg", tag); std::printf("%s %.17g\n", key, yg);
+    try {
+        const auto all = gp.predict_with_grad(x0);
+        std::snprintf(key, sizeof key, "%s_gs2", tag); pv(key, std::get<3>(all));
+        std::snprintf(key, sizeof key, "%s_gy2", tag); pv(key, std::get<2>(all));
+        VectorXd gs;
+        const double sg = gp.predict_s2_with_grad(x0, gs);
+        std::snprintf(key, sizeof key, "%s_sg", tag); std::printf("%s %.17g\n", key, sg);
+    } catch (const std::logic_error& e) {
+        std::snprintf(key, sizeof key, "%s_gs2_unsupported", tag); std::printf("%s 1\n", key);
+    }
 }
 
 int main(int argc, char** argv) {

@@ -80,6 +80,33 @@ def test_exact_nll_grad_vs_oracle(gpx, cov, n, d):
     mu, s2 = ctx.predict(Xs)
     mu_o, s2_o = oracle.ExactState(cov, X, y, hyp).predict(Xs)
     assert rel(mu, mu_o) <= 1e-9 and rel(s2, s2_o) <= 1e-9
+    # predictive input gradients (GP.cpp:284-296, 305-313, 324-333)
+    mu_g, s2_g, gmu, gs2 = ctx.predict_with_grad(Xs)
+    _, _, gmu_o, gs2_o = oracle.ExactState(cov, X, y, hyp).predict(Xs, grad=True)
+    assert np.array_equal(mu_g, mu) and rel(s2_g, s2_o) <= 1e-9
+    assert rel(gmu, gmu_o) <= 1e-9 and rel(gs2, gs2_o) <= 1e-8
+    ctx.close()
+
+
+def test_exact_predict_grad_chunked_and_finite_difference(gpx):
+    """more test points than one predict chunk, and the gradients against central differences"""
+    n, d, t = 400, 4, 1100
+    X, y, hyp, Xs = synth.make_problem(1, n, d, t)
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    ctx.prepare(gpx.MODEL_EXACT, 0, hyp)
+    mu, s2, gmu, gs2 = ctx.predict_with_grad(Xs)
+    mu_o, s2_o, gmu_o, gs2_o = oracle.ExactState(0, X, y, hyp).predict(Xs, grad=True)
+    assert rel(mu, mu_o) <= 1e-9 and rel(s2, s2_o) <= 1e-9
+    assert rel(gmu, gmu_o) <= 1e-9 and rel(gs2, gs2_o) <= 1e-8
+    h = 1e-5
+    for k in range(d):
+        E = np.zeros_like(Xs)
+        E[:, k] = h
+        mp, sp = ctx.predict(Xs + E)
+        mm, sm = ctx.predict(Xs - E)
+        assert np.max(np.abs((mp - mm) / (2 * h) - gmu[:, k])) <= 1e-6 * max(1.0, np.max(np.abs(gmu)))
+        assert np.max(np.abs((sp - sm) / (2 * h) - gs2[:, k])) <= 1e-6 * max(1.0, np.max(np.abs(gs2)))
     ctx.close()
 
 

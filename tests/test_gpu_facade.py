@@ -68,6 +68,14 @@ def test_facade_fixed_hypers_match_oracle(workdir):
         mu_o, s2_o = st().predict(Xs)[:2]
         assert rel(r[f"{tag}_mu"], mu_o) <= 1e-9 and rel(r[f"{tag}_s2"], s2_o) <= 1e-8
         assert abs(r[f"{tag}_single"][0] - mu_o[0]) <= 1e-9 * abs(mu_o[0])
+        pg = st().predict(Xs[:1], grad=True)                      # predict*_with_grad, GP.h:106-115
+        assert rel(r[f"{tag}_gy"], pg[2][0]) <= 1e-8 and abs(r[f"{tag}_yg"][0] - mu_o[0]) <= 1e-9 * abs(mu_o[0])
+        if tag == "vfe":
+            assert r["vfe_gs2_unsupported"][0] == 1               # VFE.cpp:109-112
+        else:
+            # FITC: difference of two solves against Kuu + 1e-8 I on values ~1e-17: cond(Kuu)-limited
+            assert rel(r[f"{tag}_gs2"], pg[3][0]) <= (1e-7 if tag == "gp" else 1e-5) and np.array_equal(r[f"{tag}_gy2"], r[f"{tag}_gy"])
+            assert abs(r[f"{tag}_sg"][0] - s2_o[0]) <= 1e-8 * abs(s2_o[0])
     Kiso = oracle.cov_k(1, np.array([0.3, 0.1]), X[:5], X[:7])
     assert rel(r["iso_k"], Kiso.T.ravel()) < 1e-14               # column-major 5 x 7
     assert r["llt_spd"][0] == 1 and r["llt_inv_err"][0] < 1e-9

@@ -66,6 +66,18 @@ def test_sparse_nll_grad_predict_vs_oracle(gpx, model, cov, n, d, m, jit):
     mu, s2 = ctx.predict(Xs)
     mu_o, s2_o = st.predict(Xs)
     assert rel(mu, mu_o) <= 1e-9 and rel(s2, s2_o) <= 1e-9
+    # predictive input gradients (FITC.cpp:118-129; VFE.cpp:118-123 has the mean gradient only)
+    if model == "fitc":
+        mu_g, s2_g, gmu, gs2 = ctx.predict_with_grad(Xs)
+        _, _, gmu_o, gs2_o = st.predict(Xs, grad=True)
+        assert rel(gs2, gs2_o) <= 1e-7, rel(gs2, gs2_o)
+    else:
+        with pytest.raises(gpx.GpxError):
+            ctx.predict_with_grad(Xs)
+        mu_g, s2_g, gmu, _ = ctx.predict_with_grad(Xs, want_gs2=False)
+        _, _, gmu_o = st.predict(Xs, grad=True)
+    assert rel(mu_g, mu_o) <= 1e-9 and rel(s2_g, s2_o) <= 1e-9
+    assert rel(gmu, gmu_o) <= 1e-8
     ctx.close()
 
 
