@@ -15,7 +15,15 @@ int gpx_ctx_create(int device, gpx_ctx** out) {
     gpx_ctx* c = new (std::nothrow) gpx_ctx();
     if (!c) return GPX_ERR_HIP;
     c->dev = device;
-    HIP_TRY(hipStreamCreate(&c->st));
+    // non-blocking: no implicit ordering against the caller's NULL-stream work (e.g. a collective a
+    // framework issues from the all-reduce hook); every entry point drains its own streams
+    HIP_TRY(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    // the side stream carries short dependent chains that run beside a chip-filling GEMM: highest
+    // priority, so that their workgroups take the next CU slot that frees up
+    int prio_lo = 0, prio_hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIP_TRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, prio_hi));
+    for (auto& e : c->ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->info), 64));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->host_scal), 1024 * sizeof(double)));
     int rc = c->scal.ensure(1024);
@@ -29,6 +37,7 @@ int gpx_ctx_destroy(gpx_ctx* c) {
     if (!c) return GPX_OK;
     (void)hipSetDevice(c->dev);
     (void)hipStreamSynchronize(c->st);
+    if (c->st2) (void)hipStreamSynchronize(c->st2);
     DevBuf* bufs[] = {&c->X, &c->y, &c->U, &c->Xt, &c->Ut, &c->A, &c->W, &c->T, &c->Wd, &c->r, &c->alpha,
                       &c->nalpha, &c->scal, &c->trace_ws, &c->Kxu, &c->V, &c->Bm, &c->Cm, &c->Kuu, &c->Lu,
                       &c->Am, &c->LA, &c->Winv_u, &c->Winv_A, &c->Kuu_inv, &c->A_inv, &c->Wuu, &c->Tm,
@@ -40,6 +49,9 @@ int gpx_ctx_destroy(gpx_ctx* c) {
     if (c->info) (void)hipFree(c->info);
     if (c->host_scal) (void)hipHostFree(c->host_scal);
     (void)hipStreamDestroy(c->st);
+    if (c->st2) (void)hipStreamDestroy(c->st2);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
     delete c;
     return GPX_OK;
 }

@@ -14,105 +14,98 @@ namespace {
 constexpr int NB = GPX_NB0;
 constexpr int SP = NB + 1;  // padded LDS stride
 
-// Factor one nb x nb (nb <= 64) diagonal block in LDS; write L back and W = L^-1 to Wd (64x64, ld 64).
-__global__ __launch_bounds__(256) void potrf_base_kernel(double* __restrict__ A, long lda, int nb,
-                                                         double* __restrict__ Wd, int* __restrict__ info) {
-    __shared__ double S[NB * SP];  // S[j*SP + i] = element (i, j)
-    __shared__ double Wm[NB * SP];
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx % NB, j = idx / NB;
-        double v = (i == j) ? 1.0 : 0.0;  // identity padding for partial blocks
-        if (i < nb && j < nb) v = (i >= j) ? A[i + (long)j * lda] : 0.0;
-        S[j * SP + i] = v;
-    }
-    __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        if (tid == 0) {
-            const double p = S[j * SP + j];
-            if (!(p > 0.0)) *info = 1;  // Eigen::LLT reports NumericalIssue on a pivot <= 0
-            S[j * SP + j] = sqrt(p);
-        }
-        __syncthreads();
-        const double dinv = 1.0 / S[j * SP + j];
-        const double djj = S[j * SP + j];
-        if (tid > j && tid < nb) S[j * SP + tid] = S[j * SP + tid] / djj;
-        (void)dinv;
-        __syncthreads();
-        const int t = nb - 1 - j;
-        for (int idx = tid; idx < t * t; idx += 256) {
-            const int ii = idx % t, kk = idx / t;
-            if (ii >= kk) S[(j + 1 + kk) * SP + j + 1 + ii] -= S[j * SP + j + 1 + ii] * S[j * SP + j + 1 + kk];
-        }
-        __syncthreads();
-    }
-    for (int idx = tid; idx < nb * nb; idx += 256) {
-        const int i = idx % nb, j = idx / nb;
-        if (i >= j) A[i + (long)j * lda] = S[j * SP + i];
-    }
-    // W = L^-1 by forward substitution, one column per thread (identity-padded to 64)
-    if (tid < NB) {
-        const int c = tid;
-        for (int i = 0; i < c; ++i) Wm[c * SP + i] = 0.0;
-        Wm[c * SP + c] = 1.0 / S[c * SP + c];
-        for (int i = c + 1; i < NB; ++i) {
-            double s = 0.0;
-            for (int k = c; k < i; ++k) s = fma(S[k * SP + i], Wm[c * SP + k], s);
-            Wm[c * SP + i] = -s / S[i * SP + i];
-        }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx % NB, j = idx / NB;
-        Wd[i + j * NB] = Wm[j * SP + i];
-    }
-}
-
-__device__ __forceinline__ double lane_bcast(double v, int lane) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// One WAVE factors a 64x64 (identity-padded) diagonal block held in registers: lane i owns row i.
-// Column values are broadcast with v_readlane (no LDS, no barriers).  Writes L over the lower
-// triangle of A and W = L^-1 (lower, zeros above) to W with leading dimension ldw.
-__global__ __launch_bounds__(64) void potrf_base_reg_kernel(double* __restrict__ A, long lda, int nb,
-                                                            double* __restrict__ W, long ldw, int wfull,
-                                                            int* __restrict__ info) {
-    const int i = threadIdx.x;
-    double a[NB];
+// Factor AND invert one nb x nb (nb <= 64, identity-padded to 64) diagonal block in ONE workgroup.
+// Right-looking elimination on the register-resident pair [S | E]: thread (tr, tc) owns the 4x4 tile
+// rows 4tr.., columns 4tc.. of both the Schur complement S and of E (initially I).  Step j needs only
+// column j of S and row j of E; their owners publish them to a double-buffered LDS vector during
+// step j-1 (look-ahead), so a step costs ONE barrier:  S_ik -= S_ij S_kj / d_j,  E_i: -= (S_ij/d_j) E_j:.
+// At the end L_ij = S_ij / sqrt(d_j) and W = L^-1 = diag(1/sqrt(d)) E.  Writes L over the lower
+// triangle of A and W (lower, zeros above) with leading dimension ldw.
+__global__ __launch_bounds__(256) void potrf_base_tile_kernel(double* __restrict__ A, long lda, int nb,
+                                                              double* __restrict__ W, long ldw, int wfull,
+                                                              int* __restrict__ info) {
+    __shared__ __align__(16) double colbuf[2][NB];
+    __shared__ __align__(16) double rowbuf[2][NB];
+    __shared__ double dvec[NB];
+    const int tid = threadIdx.x, tr = tid & 15, tc = tid >> 4;
+    const int r0 = 4 * tr, c0 = 4 * tc;
+    double s[4][4], e[4][4];  // [a][b] = element (r0 + a, c0 + b)
 #pragma unroll
-    for (int k = 0; k < NB; ++k) a[k] = (i < nb && k < nb && k <= i) ? A[i + (long)k * lda] : ((i == k) ? 1.0 : 0.0);
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int i = r0 + a, k = c0 + b;
+            e[a][b] = (i == k) ? 1.0 : 0.0;
+            s[a][b] = (i < nb && k < nb && k <= i) ? A[i + (long)k * lda] : e[a][b];
+        }
+    if (tc == 0)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) colbuf[0][r0 + a] = s[a][0];
+    if (tr == 0)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) rowbuf[0][c0 + b] = e[0][b];
+    __syncthreads();
     bool bad = false;
+    for (int jt = 0; jt < NB / 4; ++jt) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const double piv = lane_bcast(a[j], j);
-        bad = bad || !(piv > 0.0);  // Eigen::LLT: NumericalIssue on a pivot <= 0
-        const double rs = sqrt(piv);
-        a[j] = (i == j) ? rs : a[j] / rs;
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * jt + jj;
+            const double* cb = colbuf[jj & 1];
+            const double* rb = rowbuf[jj & 1];
+            const double piv = cb[j];
+            bad = bad || !(piv > 0.0);  // Eigen::LLT: NumericalIssue on a pivot <= 0
+            const double inv = 1.0 / piv;
+            double li[4], lk[4], mi[4], rj[4];
 #pragma unroll
-        for (int k = j + 1; k < NB; ++k) a[k] = fma(-a[j], lane_bcast(a[j], k), a[k]);
+            for (int a = 0; a < 4; ++a) {
+                li[a] = (r0 + a > j) ? cb[r0 + a] : 0.0;
+                mi[a] = li[a] * inv;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                lk[b] = (c0 + b > j) ? cb[c0 + b] * inv : 0.0;
+                rj[b] = rb[c0 + b];
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    s[a][b] = fma(-li[a], lk[b], s[a][b]);
+                    e[a][b] = fma(-mi[a], rj[b], e[a][b]);
+                }
+            if (tid == 0) dvec[j] = piv;
+            // look-ahead: publish column j+1 of S and row j+1 of E for the next step
+            const int jn = j + 1, bn = (jj + 1) & 3, tn = jn >> 2;
+            if (jn < NB) {
+                double* cbn = colbuf[(jj + 1) & 1];
+                double* rbn = rowbuf[(jj + 1) & 1];
+                if (tc == tn)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) cbn[r0 + a] = s[a][bn];
+                if (tr == tn)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) rbn[c0 + b] = e[bn][b];
+            }
+            __syncthreads();
+        }
     }
-    if (bad && i == 0) *info = 1;
+    if (bad && tid == 0) *info = 1;
+    double sc[4], sr[4];
 #pragma unroll
-    for (int k = 0; k < NB; ++k)
-        if (i < nb && k < nb && k <= i) A[i + (long)k * lda] = a[k];
-    // column c = lane of W = L^-1 by forward substitution; L_ik comes from lane i, register k
-    const int c = i;
-    double w[NB];
+    for (int b = 0; b < 4; ++b) sc[b] = sqrt(dvec[c0 + b]);
 #pragma unroll
-    for (int r = 0; r < NB; ++r) {
-        double s = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) s = fma(-lane_bcast(a[k], r), w[k], s);
-        w[r] = s / lane_bcast(a[r], r);
-    }
+    for (int a = 0; a < 4; ++a) sr[a] = 1.0 / sqrt(dvec[r0 + a]);
     const int lim = wfull ? NB : nb;
 #pragma unroll
-    for (int r = 0; r < NB; ++r)
-        if (r < lim && c < lim) W[r + (long)c * ldw] = (r >= c) ? w[r] : 0.0;
+    for (int b = 0; b < 4; ++b) {
+        const double ic = 1.0 / sc[b];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int i = r0 + a, k = c0 + b;
+            if (i < nb && k < nb && k <= i) A[i + (long)k * lda] = (i == k) ? sc[b] : s[a][b] * ic;
+            if (i < lim && k < lim) W[i + (long)k * ldw] = (i >= k) ? e[a][b] * sr[a] : 0.0;
+        }
+    }
 }
 
 // B (M x nb) <- B * W^T with W = inverse of a base block (lower): the TRSM X L^T = B
@@ -219,7 +212,7 @@ int trsm_right_rec(hipStream_t st, long M, long n1, const double* L, long ldl, c
 
 int potrf_rec(hipStream_t st, long n, double* A, long lda, double* Wd, int* info) {
     if (n <= NB) {
-        hipLaunchKernelGGL(potrf_base_reg_kernel, dim3(1), dim3(64), 0, st, A, lda, (int)n, Wd, (long)NB, 1, info);
+        hipLaunchKernelGGL(potrf_base_tile_kernel, dim3(1), dim3(256), 0, st, A, lda, (int)n, Wd, (long)NB, 1, info);
         return GPX_OK;
     }
     const long n1 = split(n), n2 = n - n1;
@@ -253,7 +246,7 @@ int trtri_rec(hipStream_t st, long n, const double* L, long ldl, double* W, long
 // is overwritten by W21, so there is no triangular solve and no small kernel besides the 64x64 base.
 int potrf_inv_rec(hipStream_t st, long n, double* A, long lda, double* W, long ldw, double* T, int* info) {
     if (n <= NB) {
-        hipLaunchKernelGGL(potrf_base_reg_kernel, dim3(1), dim3(64), 0, st, A, lda, (int)n, W, ldw, 0, info);
+        hipLaunchKernelGGL(potrf_base_tile_kernel, dim3(1), dim3(256), 0, st, A, lda, (int)n, W, ldw, 0, info);
         return GPX_OK;
     }
     const long n1 = split(n), n2 = n - n1;

@@ -27,6 +27,10 @@ struct DevBuf {
 struct gpx_ctx {
     int dev = 0;
     hipStream_t st = nullptr;
+    // side stream + events: the m x m factor chains of the sparse models run here, concurrently
+    // with row-local work that does not depend on them (sparse.hip)
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
     // training data (device): X is d x n as given, y length n
     long n = 0, m = 0;
     int d = 0, dpad = 0;

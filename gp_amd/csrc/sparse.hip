@@ -254,9 +254,12 @@ struct Sparse {
         hipLaunchKernelGGL(sum_partials_kernel, dim3(PW), dim3(256), 0, st, part(), (int)nblk(count), out, nout);
         return GPX_OK;
     }
-    int allreduce(double* buf, long count) {
+    // ready: event after which buf is complete (work queued behind it keeps running during the
+    // collective); without one the whole stream is drained first
+    int allreduce(double* buf, long count, hipEvent_t ready = nullptr) {
         if (!c->allreduce) return GPX_OK;
-        HIP_TRY(hipStreamSynchronize(st));
+        if (ready) HIP_TRY(hipEventSynchronize(ready));
+        else HIP_TRY(hipStreamSynchronize(st));
         return c->allreduce(buf, count, c->allreduce_user) ? GPX_ERR_STATE : GPX_OK;
     }
     // full symmetric inverse of a factored m x m matrix: Winv = L^-1, Inv = Winv^T Winv
@@ -277,7 +280,9 @@ struct Sparse {
         return GPX_OK;
     }
     // inputs, Kuu (+jitter on its diagonal) factored into Lu, Kxu
-    int kernels(double kuu_jitter, bool fused_inverse = false) {
+    // overlap: the Lu factor+inverse chain (one workgroup wide for most of its length) runs on the
+    // side stream while the main stream builds Kxu.
+    int kernels(double kuu_jitter, bool fused_inverse = false, bool overlap = false) {
         int rc;
         if ((rc = gpx_scale_inputs(st, c->X.p, n, d, c->dpad, h.sc, c->Xt.p, c->ldx))) return rc;
         if ((rc = gpx_scale_inputs(st, c->U.p, m, d, c->dpad, h.sc, c->Ut.p, c->ldu))) return rc;
@@ -286,8 +291,23 @@ struct Sparse {
         HIP_TRY(hipMemcpyAsync(c->Lu.p, c->Kuu.p, (size_t)ldm * m * sizeof(double), hipMemcpyDeviceToDevice, st));
         HIP_TRY(hipMemsetAsync(c->info, 0, 2 * sizeof(int), st));
         if (fused_inverse) {
-            HIP_TRY(hipMemsetAsync(c->Winv_u.p, 0, (size_t)ldm * m * sizeof(double), st));
-            if ((rc = gpx_potrf_inv(st, m, c->Lu.p, ldm, c->Winv_u.p, ldm, c->T.p, c->info))) return rc;
+            hipStream_t sf = st;
+            if (overlap) {
+                // the chain below is host-launch-bound: queue the independent row-local work first
+                sf = c->st2;
+                HIP_TRY(hipEventRecord(c->ev[0], st));
+                HIP_TRY(hipStreamWaitEvent(sf, c->ev[0], 0));
+                if ((rc = gpx_cov_build(st, c->Xt.p, c->ldx, n, c->Ut.p, c->ldu, m, c->dpad, h.sf2, c->Kxu.p, ldn, 0, 0.0)))
+                    return rc;
+                if ((rc = gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p))) return rc;
+            }
+            HIP_TRY(hipMemsetAsync(c->Winv_u.p, 0, (size_t)ldm * m * sizeof(double), sf));
+            if ((rc = gpx_potrf_inv(sf, m, c->Lu.p, ldm, c->Winv_u.p, ldm, c->T.p, c->info))) return rc;
+            if (overlap) {
+                HIP_TRY(hipEventRecord(c->ev[1], sf));
+                HIP_TRY(hipStreamWaitEvent(st, c->ev[1], 0));
+                return GPX_OK;
+            }
         } else if ((rc = gpx_potrf(st, m, c->Lu.p, ldm, c->Wd_u.p, c->info))) {
             return rc;
         }
@@ -314,7 +334,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     const HypView& h = s.h;
     const long n = s.n, m = s.m, ldn = s.ldn, ldm = s.ldm;
     const int d = s.d, nh = h.nk + 2;
-    hipStream_t st = c->st;
+    hipStream_t st = c->st;  // main stream; phase 2 switches to the side stream
     const bool fitc = model == GPX_MODEL_FITC;
     double* red = c->red.p;          // [m*m | m | tail]
     double* redF = red + m * m;
@@ -329,7 +349,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     if (calc_grad) memset(grad, 0, sizeof(double) * nh);  // FITC.cpp:232 / VFE.cpp:194 on failure
 
     // ---- phase 1 ------------------------------------------------------------------------------
-    if ((rc = s.kernels(jitter, true))) return rc;  // Lu diag + Winv_u = Lu^-1
+    if ((rc = s.kernels(jitter, true, true))) return rc;  // Lu diag + Winv_u = Lu^-1
     HIP_TRY(hipMemsetAsync(redT, 0, 16 * sizeof(double), st));
     const double* Sop = fitc ? Ksc : c->Kxu.p;
     if (fitc) {
@@ -348,10 +368,20 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     // S = Kux [Gamma^-1] Kxu, lower tiles, split-K over the training rows (FITC.cpp:217, VFE.cpp:173)
     if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, Sop, ldn, c->Kxu.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap)))
         return rc;
-    if ((rc = s.allreduce(red, m * m + m + 16))) return rc;
+    HIP_TRY(hipEventRecord(c->ev[0], st));
+    if (fitc && calc_grad) {
+        // B = Kxu Kuu^-1 = V Lu^-1 (FITC.cpp:214) does not depend on A: it keeps the GPU full while the
+        // all-reduce and the (narrow) factor chain of A run beside it
+        if ((rc = gpx_gemm(st, 0, 1, n, m, m, 1.0, c->V.p, ldn, c->Winv_u.p, ldm, 0.0, c->Bm.p, ldn, GEMM_KLO_N))) return rc;
+    }
+    if ((rc = s.allreduce(red, m * m + m + 16, c->ev[0]))) return rc;
 
-    // ---- phase 2 ------------------------------------------------------------------------------
+    // ---- phase 2 (side stream) ------------------------------------------------------------------
     // A = sn2*Kuu + S (FITC.cpp:217, VFE.cpp:174), factor, a = A^-1 F
+    const hipStream_t st_main = st;
+    st = c->st2;
+    s.st = st;
+    HIP_TRY(hipStreamWaitEvent(st, c->ev[0], 0));
     hipLaunchKernelGGL(mm_combine_lower_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, h.sn2, c->Kuu.p, ldm, 1.0, red, m,
                        0.0, c->Am.p, ldm);
     HIP_TRY(hipMemcpyAsync(c->LA.p, c->Am.p, (size_t)ldm * m * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -373,7 +403,9 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     HIP_TRY(hipMemcpyAsync(hs, c->scal.p, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hs + 8, redT, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hs + 16, c->info, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipStreamSynchronize(st));  // the side stream is drained: phase 3 needs no event
+    st = st_main;
+    s.st = st;
     int info[2];
     memcpy(info, hs + 16, sizeof(info));
     const double ntot = hs[8 + 2];
@@ -389,7 +421,10 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         v = 0.5 * ntot * log(2 * M_PI) + 0.5 * (ldA - ldU + (ntot - (double)m) * log(h.sn2)) +
             0.5 * (hs[8 + 0] - Fa) / h.sn2 + f_tr;                                           // VFE.cpp:185-189
     }
-    if (info[0] != 0 || info[1] != 0 || !std::isfinite(v)) return GPX_OK;  // NLL = INF, g = 0
+    if (info[0] != 0 || info[1] != 0 || !std::isfinite(v)) {
+        HIP_TRY(hipStreamSynchronize(st));  // B may still be running
+        return GPX_OK;                      // NLL = INF, g = 0
+    }
     *nll = v;
     if (!calc_grad) return GPX_OK;
 
@@ -408,7 +443,6 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         // C = Gamma^-1 Kxu A^-1 (FITC.cpp:262) and B = Kxu Kuu^-1 = V Lu^-1 (FITC.cpp:214)
         double* Cm = c->Tm.p;
         if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, Ksc, ldn, c->A_inv.p, ldm, 0.0, Cm, ldn, 0))) return rc;
-        if ((rc = gpx_gemm(st, 0, 1, n, m, m, 1.0, c->V.p, ldn, c->Winv_u.p, ldm, 0.0, c->Bm.p, ldn, GEMM_KLO_N))) return rc;
         double* c2coef = c->vn[3].p;
         double* ucoef = c->vn[4].p;
         double* wv = c->vn[5].p;
