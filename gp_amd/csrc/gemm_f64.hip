@@ -13,6 +13,7 @@
 // lane index (lane & 15) runs along M: accumulator stores and the beta*C read are 128-B
 // contiguous per 16 lanes in the column-major C.
 #include "gpx_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         bi = tile % g.tiles_m;
         bj = tile / g.tiles_m;
     }
-    const int m0 = bi * BM, n0 = bj * BN;
+    const int m0 = __builtin_amdgcn_readfirstlane(bi * BM), n0 = __builtin_amdgcn_readfirstlane(bj * BN);
 
     int klo = 0, khi = g.K;
     if (g.flags & GEMM_KLO_M) klo = max(klo, m0);
@@ -144,35 +145,87 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const bool tfA = g.fastA && (m0 + BM <= g.M);
     const bool tfB = g.fastB && (n0 + BN <= g.N);
     v2d ra[BM / 32], rb[BN / 32];
-    if (kt0 < kt1) {
-        const int k0 = klo + kt0 * BK;
-        const bool kin = k0 + BK <= g.K;
-        gload<BM, AKC>(g.A, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
-        gload<BN, BKC>(g.B, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
-    }
-    for (int kt = kt0; kt < kt1; ++kt) {
-        __syncthreads();
-        sstore<BM, AKC>(sA, ra);
-        sstore<BN, BKC>(sB, rb);
-        __syncthreads();
-        if (kt + 1 < kt1) {
-            const int k0 = klo + (kt + 1) * BK;
+    const int tid = threadIdx.x;
+    // Interior tiles (every operand tile of the K range is full and 16-B aligned; true for all but the
+    // edge tiles) take a loop whose load phase is 16 global loads and nothing else: a uniform 64-bit
+    // base per operand that advances by one K tile per step (scalar ALU) plus ONE loop-invariant
+    // 32-bit byte offset per thread.  Vector instructions issued next to the MFMAs of the co-resident
+    // wave delay them, so the address arithmetic of the generic path below costs matrix-pipe time.
+    const bool interior = tfA && tfB && (klo + kt1 * BK <= g.K) && kt0 < kt1;
+    if (interior) {
+        const long k00 = klo + kt0 * BK;
+        const char* pa = reinterpret_cast<const char*>(g.A) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
+        const char* pb = reinterpret_cast<const char*>(g.B) + (BKC ? k00 + (long)n0 * g.ldb : n0 + k00 * g.ldb) * 8;
+        const long ia = (AKC ? 32 * g.lda : (512 / BM) * g.lda) * 8;  // between a thread's consecutive loads
+        const long ib = (BKC ? 32 * g.ldb : (512 / BN) * g.ldb) * 8;
+        const long ka = (AKC ? (long)BK : BK * g.lda) * 8;            // per K tile
+        const long kb = (BKC ? (long)BK : BK * g.ldb) * 8;
+        const unsigned ta = (unsigned)((AKC ? 2 * (tid & 7) + (long)(tid >> 3) * g.lda
+                                            : 2 * (tid % (BM / 2)) + (long)(tid / (BM / 2)) * g.lda) * 8);
+        const unsigned tb = (unsigned)((BKC ? 2 * (tid & 7) + (long)(tid >> 3) * g.ldb
+                                            : 2 * (tid % (BN / 2)) + (long)(tid / (BN / 2)) * g.ldb) * 8);
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) ra[i] = *reinterpret_cast<const v2d*>(pa + i * ia + ta);
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) rb[i] = *reinterpret_cast<const v2d*>(pb + i * ib + tb);
+        for (int kt = kt0; kt < kt1; ++kt) {
+            __syncthreads();
+            sstore<BM, AKC>(sA, ra);
+            sstore<BN, BKC>(sB, rb);
+            __syncthreads();
+            if (kt + 1 < kt1) {
+                pa += ka;
+                pb += kb;
+#pragma unroll
+                for (int i = 0; i < BM / 32; ++i) ra[i] = *reinterpret_cast<const v2d*>(pa + i * ia + ta);
+#pragma unroll
+                for (int i = 0; i < BN / 32; ++i) rb[i] = *reinterpret_cast<const v2d*>(pb + i * ib + tb);
+            }
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                double fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = sfrag<BM, AKC>(sA, wm + i * 16 + l15, kk * 4 + l4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = sfrag<BN, BKC>(sB, wn + j * 16 + l15, kk * 4 + l4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
+            }
+        }
+    } else {
+        if (kt0 < kt1) {
+            const int k0 = klo + kt0 * BK;
             const bool kin = k0 + BK <= g.K;
             gload<BM, AKC>(g.A, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
             gload<BN, BKC>(g.B, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
         }
+        for (int kt = kt0; kt < kt1; ++kt) {
+            __syncthreads();
+            sstore<BM, AKC>(sA, ra);
+            sstore<BN, BKC>(sB, rb);
+            __syncthreads();
+            if (kt + 1 < kt1) {
+                const int k0 = klo + (kt + 1) * BK;
+                const bool kin = k0 + BK <= g.K;
+                gload<BM, AKC>(g.A, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
+                gload<BN, BKC>(g.B, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
+            }
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            double fa[TM], fb[TN];
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                double fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = sfrag<BM, AKC>(sA, wm + i * 16 + l15, kk * 4 + l4);
+                for (int i = 0; i < TM; ++i) fa[i] = sfrag<BM, AKC>(sA, wm + i * 16 + l15, kk * 4 + l4);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = sfrag<BN, BKC>(sB, wn + j * 16 + l15, kk * 4 + l4);
+                for (int j = 0; j < TN; ++j) fb[j] = sfrag<BN, BKC>(sB, wn + j * 16 + l15, kk * 4 + l4);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
+            }
         }
     }
 
