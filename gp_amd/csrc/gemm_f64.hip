@@ -34,13 +34,13 @@ struct GemmArgs {
 constexpr int BK = 16;
 
 // global -> registers: BMN*BK doubles per operand tile, BMN/32 double2 per thread
-template <int BMN, bool KC>
+template <int BMN, bool KC, int NT = 256>
 __device__ __forceinline__ void gload(const double* __restrict__ P, long ld, int mn0, int k0, int MN,
-                                      int kend, bool fast, v2d (&r)[BMN / 32]) {
+                                      int kend, bool fast, v2d (&r)[BMN * 8 / NT]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < BMN / 32; ++i) {
-        const int e = tid + 256 * i;
+    for (int i = 0; i < BMN * 8 / NT; ++i) {
+        const int e = tid + NT * i;
         if (!KC) {
             const int m = mn0 + 2 * (e % (BMN / 2));
             const int k = k0 + e / (BMN / 2);
@@ -70,12 +70,12 @@ __device__ __forceinline__ void gload(const double* __restrict__ P, long ld, int
 // registers -> LDS.  M-contiguous image: [BK][BMN+16] (row stride = 128 B mod 256 B, so the four
 // k-rows one MFMA fragment read touches fall on disjoint banks); K-contiguous image: [BMN][BK+2]
 // (row stride 144 B = 16*9: sixteen consecutive rows cover all 16-B bank slots once).
-template <int BMN, bool KC>
-__device__ __forceinline__ void sstore(double* __restrict__ s, const v2d (&r)[BMN / 32]) {
+template <int BMN, bool KC, int NT = 256>
+__device__ __forceinline__ void sstore(double* __restrict__ s, const v2d (&r)[BMN * 8 / NT]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < BMN / 32; ++i) {
-        const int e = tid + 256 * i;
+    for (int i = 0; i < BMN * 8 / NT; ++i) {
+        const int e = tid + NT * i;
         if (!KC) {
             const int m2 = e % (BMN / 2), k = e / (BMN / 2);
             *reinterpret_cast<v2d*>(&s[k * (BMN + 16) + 2 * m2]) = r[i];
@@ -91,9 +91,14 @@ __device__ __forceinline__ double sfrag(const double* __restrict__ s, int row, i
     return KC ? s[row * (BK + 2) + k] : s[k * (BMN + 16) + row];
 }
 
-template <int TM, int TN, bool AKC, bool BKC>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
-    constexpr int BM = 32 * TM, BN = 32 * TN;
+// NW = waves per workgroup: 4 (a 2 x 2 grid of waves) or 1 (the wave is the workgroup: no barrier
+// couples it to other waves; twice the operand traffic per flop)
+template <int TM, int TN, bool AKC, bool BKC, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_kernel(const GemmArgs g) {
+    constexpr int NT = 64 * NW;
+    constexpr int WG = NW == 4 ? 2 : 1;
+    constexpr int BM = 16 * WG * TM, BN = 16 * WG * TN;
+    constexpr int NLA = BM * 8 / NT, NLB = BN * 8 / NT;  // 16-B loads per thread and operand tile
     constexpr int LA = AKC ? BM * (BK + 2) : BK * (BM + 16);
     constexpr int LB = BKC ? BN * (BK + 2) : BK * (BN + 16);
     __shared__ __attribute__((aligned(16))) double smem[LA + LB];
@@ -112,6 +117,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         while (bi * (bi + 1) / 2 > tile) --bi;
         while ((bi + 1) * (bi + 2) / 2 <= tile) ++bi;
         bj = tile - bi * (bi + 1) / 2;
+    } else if (g.flags & (GEMM_KLO_M | GEMM_KHI_M)) {
+        // K range depends on the M tile: neighbouring workgroups share it (same trip count, same A
+        // rows in L2, marching through K together) when the N index runs fastest
+        bi = tile / g.tiles_n;
+        bj = tile % g.tiles_n;
     } else {
         bi = tile % g.tiles_m;
         bj = tile / g.tiles_m;
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave & 1) * (16 * TM), wn = (wave >> 1) * (16 * TN);
+    const int wm = NW == 4 ? (wave & 1) * (16 * TM) : 0, wn = NW == 4 ? (wave >> 1) * (16 * TN) : 0;
     const int l15 = lane & 15, l4 = lane >> 4;
 
     v4d acc[TN][TM];
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 
     const bool tfA = g.fastA && (m0 + BM <= g.M);
     const bool tfB = g.fastB && (n0 + BN <= g.N);
-    v2d ra[BM / 32], rb[BN / 32];
+    v2d ra[NLA], rb[NLB];
     const int tid = threadIdx.x;
     // Interior tiles (every operand tile of the K range is full and 16-B aligned; true for all but the
     // edge tiles) take a loop whose load phase is 16 global loads and nothing else: a uniform 64-bit
@@ -156,8 +166,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         const long k00 = klo + kt0 * BK;
         const char* pa = reinterpret_cast<const char*>(g.A) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
         const char* pb = reinterpret_cast<const char*>(g.B) + (BKC ? k00 + (long)n0 * g.ldb : n0 + k00 * g.ldb) * 8;
-        const long ia = (AKC ? 32 * g.lda : (512 / BM) * g.lda) * 8;  // between a thread's consecutive loads
-        const long ib = (BKC ? 32 * g.ldb : (512 / BN) * g.ldb) * 8;
+        const long ia = (AKC ? (NT / 8) * g.lda : (2 * NT / BM) * g.lda) * 8;  // between a thread's consecutive loads
+        const long ib = (BKC ? (NT / 8) * g.ldb : (2 * NT / BN) * g.ldb) * 8;
         const long ka = (AKC ? (long)BK : BK * g.lda) * 8;            // per K tile
         const long kb = (BKC ? (long)BK : BK * g.ldb) * 8;
         const unsigned ta = (unsigned)((AKC ? 2 * (tid & 7) + (long)(tid >> 3) * g.lda
@@ -165,21 +175,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         const unsigned tb = (unsigned)((BKC ? 2 * (tid & 7) + (long)(tid >> 3) * g.ldb
                                             : 2 * (tid % (BN / 2)) + (long)(tid / (BN / 2)) * g.ldb) * 8);
 #pragma unroll
-        for (int i = 0; i < BM / 32; ++i) ra[i] = *reinterpret_cast<const v2d*>(pa + i * ia + ta);
+        for (int i = 0; i < NLA; ++i) ra[i] = *reinterpret_cast<const v2d*>(pa + i * ia + ta);
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) rb[i] = *reinterpret_cast<const v2d*>(pb + i * ib + tb);
+        for (int i = 0; i < NLB; ++i) rb[i] = *reinterpret_cast<const v2d*>(pb + i * ib + tb);
         for (int kt = kt0; kt < kt1; ++kt) {
             __syncthreads();
-            sstore<BM, AKC>(sA, ra);
-            sstore<BN, BKC>(sB, rb);
+            sstore<BM, AKC, NT>(sA, ra);
+            sstore<BN, BKC, NT>(sB, rb);
             __syncthreads();
             if (kt + 1 < kt1) {
                 pa += ka;
                 pb += kb;
 #pragma unroll
-                for (int i = 0; i < BM / 32; ++i) ra[i] = *reinterpret_cast<const v2d*>(pa + i * ia + ta);
+                for (int i = 0; i < NLA; ++i) ra[i] = *reinterpret_cast<const v2d*>(pa + i * ia + ta);
 #pragma unroll
-                for (int i = 0; i < BN / 32; ++i) rb[i] = *reinterpret_cast<const v2d*>(pb + i * ib + tb);
+                for (int i = 0; i < NLB; ++i) rb[i] = *reinterpret_cast<const v2d*>(pb + i * ib + tb);
             }
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
@@ -199,19 +209,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         if (kt0 < kt1) {
             const int k0 = klo + kt0 * BK;
             const bool kin = k0 + BK <= g.K;
-            gload<BM, AKC>(g.A, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
-            gload<BN, BKC>(g.B, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
+            gload<BM, AKC, NT>(g.A, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
+            gload<BN, BKC, NT>(g.B, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
         }
         for (int kt = kt0; kt < kt1; ++kt) {
             __syncthreads();
-            sstore<BM, AKC>(sA, ra);
-            sstore<BN, BKC>(sB, rb);
+            sstore<BM, AKC, NT>(sA, ra);
+            sstore<BN, BKC, NT>(sB, rb);
             __syncthreads();
             if (kt + 1 < kt1) {
                 const int k0 = klo + (kt + 1) * BK;
                 const bool kin = k0 + BK <= g.K;
-                gload<BM, AKC>(g.A, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
-                gload<BN, BKC>(g.B, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
+                gload<BM, AKC, NT>(g.A, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
+                gload<BN, BKC, NT>(g.B, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
             }
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
@@ -261,12 +271,13 @@ __global__ void splitk_reduce_kernel(double* __restrict__ C, long ldc, const dou
     *c = beta == 0.0 ? s : s + beta * *c;
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int NW = 4>
 void launch(hipStream_t st, int a_kc, int b_kc, const GemmArgs& g, int grid) {
-    if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), dim3(grid), dim3(256), 0, st, g);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), dim3(grid), dim3(256), 0, st, g);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), dim3(grid), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), dim3(grid), dim3(256), 0, st, g);
+    const dim3 blk(64 * NW);
+    if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false, NW>), dim3(grid), blk, 0, st, g);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true, NW>), dim3(grid), blk, 0, st, g);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false, NW>), dim3(grid), blk, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true, NW>), dim3(grid), blk, 0, st, g);
 }
 
 // ---- optional per-launch HIP-event timing of the large GEMMs (bench.py's roofline leg) -------
@@ -297,6 +308,8 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     if (M <= 0 || N <= 0) return GPX_OK;
     if (M > 0x7fffffffL - 256 || N > 0x7fffffffL - 256 || K > 0x7fffffffL - 256) return GPX_ERR_ARG;
     if ((flags & GEMM_LOWER) && M != N) return GPX_ERR_ARG;
+    // K ranges that grow with the tile index: walk the tiles backwards so the long ones start first
+    if (!(flags & GEMM_LOWER) && (flags & (GEMM_KHI_M | GEMM_KHI_N))) flags |= GEMM_HEAVY_LAST;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -313,6 +326,8 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     }
     if (flags & GEMM_TILE64) bt = 64;
     if (flags & GEMM_TILE128) bt = 128;
+    const bool onewave = (flags & GEMM_TILE64W) != 0;
+    if (onewave) bt = 64;
     g.tiles_m = (int)((M + bt - 1) / bt);
     g.tiles_n = (int)((N + bt - 1) / bt);
     g.ntiles = (flags & GEMM_LOWER) ? g.tiles_m * (g.tiles_m + 1) / 2 : g.tiles_m * g.tiles_n;
@@ -335,7 +350,8 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
             g_prof.skipped++;
         }
     }
-    if (bt == 128) launch<4, 4>(st, a_kc, b_kc, g, (int)grid);
+    if (onewave) launch<4, 4, 1>(st, a_kc, b_kc, g, (int)grid);
+    else if (bt == 128) launch<4, 4>(st, a_kc, b_kc, g, (int)grid);
     else launch<2, 2>(st, a_kc, b_kc, g, (int)grid);
     if (g.splitk > 1) {
         const long tot = M * N;

@@ -32,6 +32,8 @@ def bench(M, N, K, a_kc, b_kc, flags=0, reps=3, name=""):
     fl = 2.0 * M * N * K
     if flags & lib.GEMM_LOWER:
         fl *= 0.5
+    if flags & (lib.GEMM_KLO_M | lib.GEMM_KLO_N | lib.GEMM_KHI_M | lib.GEMM_KHI_N):
+        fl *= (2.0 / 3.0) if flags & lib.GEMM_LOWER else 0.5   # triangular operand: n^3/3 resp. half
     print(f"{name:28s} M={M:6d} N={N:6d} K={K:6d} akc={a_kc} bkc={b_kc} flags={flags:3d}  {dt * 1e3:9.2f} ms  {fl / dt / 1e12:6.1f} TF/s", flush=True)
 
 
@@ -40,6 +42,14 @@ if __name__ == "__main__":
     if len(sys.argv) > 2:   # single case for PMC passes
         bench(n, n, n, 0, 0, name="NT", reps=2)
         sys.exit(0)
+    if len(sys.argv) <= 1 or True:
+        # the five GEMM forms of one exact-GP evaluation (chol.hip potrf_inv_rec + lauum), top level
+        h = n // 2
+        bench(h, h, h, 0, 0, lib.GEMM_KHI_N, name="L21 = A21 W11^T (KHI_N)")
+        bench(h, h, h, 0, 0, lib.GEMM_LOWER, name="A22 -= L21 L21^T (lower)")
+        bench(h, h, h, 0, 1, lib.GEMM_KLO_N, name="T = L21 W11 (KLO_N)")
+        bench(h, h, h, 0, 1, lib.GEMM_KHI_M | lib.GEMM_HEAVY_LAST, name="W21 = -W22 T (KHI_M)")
+        bench(n, n, n, 1, 1, lib.GEMM_LOWER | lib.GEMM_KLO_M, name="W^T W (lower, KLO_M)")
     bench(n, n, n, 0, 0, name="NT (potrf trsm/syrk form)")
     bench(n, n, n, 0, 0, lib.GEMM_LOWER, name="NT lower (syrk)")
     bench(n, n, n, 0, 1, name="NN (trtri)")

@@ -4,6 +4,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gp_amd/csrc -I include -c tools/probe/gemm_cached_probe.hip -o /tmp/p.o && hipcc --offload-arch=gfx950 /tmp/p.o gp_amd/csrc/obj/gemm_f64.o -o tools/probe/gemm_cached_probe
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include "gpx_internal.h"
 #include "kernels.h"
 
@@ -27,15 +28,27 @@ int main(int argc, char** argv) {
     const long ld = n + 16;
     double *A, *B, *C;
     if (hipMalloc(&A, ld * n * 8) || hipMalloc(&B, ld * n * 8) || hipMalloc(&C, n * n * 8)) return 1;
-    hipMemset(A, 0x3c, ld * n * 8);  // nonzero finite doubles (power draw of real data)
-    hipMemset(B, 0x3d, ld * n * 8);
+    if (argc > 2) {  // random operands: the data-dependent power draw of a real evaluation
+        std::vector<double> h((size_t)ld * n);
+        unsigned long long x = 88172645463325252ULL;
+        for (auto& v : h) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            v = (double)(x >> 11) / 9007199254740992.0 - 0.5;
+        }
+        hipMemcpy(A, h.data(), ld * n * 8, hipMemcpyHostToDevice);
+        for (auto& v : h) v = -v * 0.7;
+        hipMemcpy(B, h.data(), ld * n * 8, hipMemcpyHostToDevice);
+    } else {
+        hipMemset(A, 0x3c, ld * n * 8);  // constant finite doubles
+        hipMemset(B, 0x3d, ld * n * 8);
+    }
     hipStream_t st;
     hipStreamCreate(&st);
     for (int v = 0; v < 4; ++v) {
         const int akc = v >> 1, bkc = v & 1;
-        printf("akc=%d bkc=%d  real ld: %6.1f TF   ld=0 (cached operands): %6.1f TF   64x64 tiles: %6.1f TF\n", akc, bkc,
+        printf("akc=%d bkc=%d  real ld: %6.1f TF   ld=0 (cached operands): %6.1f TF   one-wave 64x64 tiles: %6.1f TF\n", akc, bkc,
                run(st, n, ld, A, B, C, akc, bkc, 0), run(st, n, 0, A, B, C, akc, bkc, 0),
-               run(st, n, ld, A, B, C, akc, bkc, GEMM_TILE64));
+               run(st, n, ld, A, B, C, akc, bkc, GEMM_TILE64W));
         fflush(stdout);
     }
     return 0;
