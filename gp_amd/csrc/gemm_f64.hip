@@ -29,6 +29,7 @@ struct GemmArgs {
     int splitk;
     long slab;     // doubles between split-K slabs
     int fastA, fastB;  // base pointer and ld allow 16-B vector loads
+    int xcd_rows;      // tall-skinny outputs: the N tiles of one M tile run on ONE XCD (see kernel)
 };
 
 constexpr int BK = 16;
@@ -110,21 +111,31 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_kernel(const GemmArgs g) {
         ks = tile % g.splitk;
         tile /= g.splitk;
     }
-    if (g.flags & GEMM_HEAVY_LAST) tile = g.ntiles - 1 - tile;
     int bi, bj;
-    if (g.flags & GEMM_LOWER) {
-        bi = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
-        while (bi * (bi + 1) / 2 > tile) --bi;
-        while ((bi + 1) * (bi + 2) / 2 <= tile) ++bi;
-        bj = tile - bi * (bi + 1) / 2;
-    } else if (g.flags & (GEMM_KLO_M | GEMM_KHI_M)) {
-        // K range depends on the M tile: neighbouring workgroups share it (same trip count, same A
-        // rows in L2, marching through K together) when the N index runs fastest
-        bi = tile / g.tiles_n;
-        bj = tile % g.tiles_n;
+    if (g.xcd_rows) {
+        // Workgroup b runs on XCD b % 8.  For a tall-skinny output (few N tiles) give each XCD its own
+        // M tiles and let that M tile's N tiles follow one another on it: the A rows are then fetched
+        // into ONE L2 once instead of once per N tile from HBM / Infinity Cache.
+        const int j = (tile >> 3) % g.tiles_n;
+        bi = ((tile >> 3) / g.tiles_n) * 8 + (tile & 7);
+        bj = j;
+        if (bi >= g.tiles_m) return;
     } else {
-        bi = tile % g.tiles_m;
-        bj = tile / g.tiles_m;
+        if (g.flags & GEMM_HEAVY_LAST) tile = g.ntiles - 1 - tile;
+        if (g.flags & GEMM_LOWER) {
+            bi = (int)((sqrt(8.0 * (double)tile + 1.0) - 1.0) * 0.5);
+            while (bi * (bi + 1) / 2 > tile) --bi;
+            while ((bi + 1) * (bi + 2) / 2 <= tile) ++bi;
+            bj = tile - bi * (bi + 1) / 2;
+        } else if (g.flags & (GEMM_KLO_M | GEMM_KHI_M)) {
+            // K range depends on the M tile: neighbouring workgroups share it (same trip count, same A
+            // rows in L2, marching through K together) when the N index runs fastest
+            bi = tile / g.tiles_n;
+            bj = tile % g.tiles_n;
+        } else {
+            bi = tile % g.tiles_m;
+            bj = tile / g.tiles_m;
+        }
     }
     const int m0 = __builtin_amdgcn_readfirstlane(bi * BM), n0 = __builtin_amdgcn_readfirstlane(bj * BN);
 
@@ -337,7 +348,8 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
         g.C = work;
         g.ldc = M;
     }
-    const long grid = (long)g.ntiles * g.splitk;
+    g.xcd_rows = (!(flags & (GEMM_LOWER | GEMM_KLO_M | GEMM_KLO_N | GEMM_KHI_M | GEMM_KHI_N)) && g.splitk == 1 && g.tiles_n <= 32 && g.tiles_m >= 64 && !(flags & GEMM_NO_XCD)) ? 1 : 0;
+    const long grid = g.xcd_rows ? (long)((g.tiles_m + 7) / 8) * 8 * g.tiles_n : (long)g.ntiles * g.splitk;
     if (grid > 0x7fffffffL) return GPX_ERR_ARG;
     const double fl = useful_flops(M, N, K, flags);
     bool timed = false;
