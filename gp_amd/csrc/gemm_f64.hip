@@ -460,11 +460,22 @@ int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, 
                     long ldc, int flags, double* work, long work_doubles) {
     int splitk = 1;
     if (work) {
-        const long tiles = ((M + 63) / 64) * ((N + 63) / 64) / ((flags & GEMM_LOWER) ? 2 : 1);
         const long kt = (K + BK - 1) / BK;
-        while (splitk < 64 && tiles * splitk < 1024 && kt / (splitk * 2) >= 16 &&
-               (long)(splitk * 2) * M * N <= work_doubles)
-            splitk *= 2;
+        // 128x128 tiles (twice the flops per operand byte) whenever enough slabs fit the workspace to
+        // fill the chip with them; 64x64 tiles otherwise
+        const long t128 = ((M + 127) / 128) * ((N + 127) / 128) / ((flags & GEMM_LOWER) ? 2 : 1);
+        int s128 = 1;
+        while (s128 < 64 && t128 * s128 < 2048 && kt / (s128 * 2) >= 32 && (long)(s128 * 2) * M * N <= work_doubles)
+            s128 *= 2;
+        if (!(flags & (GEMM_TILE64 | GEMM_TILE128)) && t128 * s128 >= 1024) {
+            flags |= GEMM_TILE128;
+            splitk = s128;
+        } else {
+            const long tiles = ((M + 63) / 64) * ((N + 63) / 64) / ((flags & GEMM_LOWER) ? 2 : 1);
+            while (splitk < 64 && tiles * splitk < 1024 && kt / (splitk * 2) >= 16 &&
+                   (long)(splitk * 2) * M * N <= work_doubles)
+                splitk *= 2;
+        }
     }
     return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, splitk, work);
 }
