@@ -253,6 +253,33 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_kernel(const GemmArgs g) {
     // epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4) + 4r]
     double* Cb = g.C + (g.splitk > 1 ? (long)ks * g.slab : 0);
     const bool plain = g.splitk > 1 || g.beta == 0.0;
+    if (m0 + BM <= g.M && n0 + BN <= g.N) {
+        // full tile: no bounds tests; with beta != 0 the old values come in batches of TM*4 loads per
+        // wait instead of one round trip per element
+        double* c0 = Cb + (m0 + wm + l15) + (long)(n0 + wn + l4) * g.ldc;
+        const long s4 = 4 * g.ldc;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            double* cj = c0 + (long)(16 * j) * g.ldc;
+            if (plain) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) cj[r * s4 + 16 * i] = g.alpha * acc[j][i][r];
+            } else {
+                double old[4][TM];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) old[r][i] = cj[r * s4 + 16 * i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) cj[r * s4 + 16 * i] = g.alpha * acc[j][i][r] + g.beta * old[r][i];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
