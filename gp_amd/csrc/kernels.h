@@ -18,6 +18,7 @@ struct TraceArgs {
     int sym;          // p == q, M1 symmetric and valid in its lower triangle: visit tiles a >= b only
     double* partial;  // filled in by gpx_pair_trace
     int ntiles, tiles_p;
+    int vec;          // M1 / M2 allow 16-B vector loads (set by gpx_pair_trace)
 };
 int gpx_scale_inputs(hipStream_t st, const double* X, long n, int d, int dpad, const ScaleArgs& sc,
                      double* Xt, long ldx);

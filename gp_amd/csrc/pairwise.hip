@@ -57,51 +57,77 @@ __device__ __forceinline__ void stage(double (*sa)[64], double (*sb)[64], const 
     }
 }
 
+// Register tiling shared by cov_build and pair_trace: thread (rg, cg) = (tid & 15, tid >> 4) owns the
+// 4 x 4 patch rows a0 + 4 rg .., columns b0 + 4 cg .. of a 64 x 64 tile.  Per dimension it reads its
+// 4 + 4 coordinates from LDS as four 16-B loads for 16 pairs (one LDS instruction per 4 pair-terms;
+// one per term with a row-per-lane mapping, which made these kernels LDS-issue-bound) and a wave's
+// 16 row groups touch 512 contiguous bytes of every output / weight column.
+__device__ __forceinline__ void patch_r2(const double (*sa)[64], const double (*sb)[64], int cw, int rg, int cg,
+                                         double (&r2)[4][4]) {
+    for (int i = 0; i < cw; ++i) {
+        const v2d a01 = *reinterpret_cast<const v2d*>(&sa[i][4 * rg]), a23 = *reinterpret_cast<const v2d*>(&sa[i][4 * rg + 2]);
+        const v2d b01 = *reinterpret_cast<const v2d*>(&sb[i][4 * cg]), b23 = *reinterpret_cast<const v2d*>(&sb[i][4 * cg + 2]);
+        const double xa[4] = {a01.x, a01.y, a23.x, a23.y}, xb[4] = {b01.x, b01.y, b23.x, b23.y};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double t = xa[r] - xb[c];
+                r2[c][r] = fma(t, t, r2[c][r]);
+            }
+    }
+}
+
 __global__ __launch_bounds__(256) void cov_build_kernel(const double* __restrict__ Xt1, long ld1, long p,
                                                         const double* __restrict__ Xt2, long ld2, long q,
                                                         int dpad, double sf2, double* __restrict__ out,
-                                                        long ldo, int lower, int tiles_p, double diag_add) {
-    __shared__ double sa[DCH][64], sb[DCH][64];
+                                                        long ldo, int lower, int tiles_p, double diag_add,
+                                                        int vec) {
+    __shared__ __attribute__((aligned(16))) double sa[DCH][64], sb[DCH][64];
     int ta, tb;
     decode_tile(blockIdx.x, lower, tiles_p, ta, tb);
     const long a0 = (long)ta * 64, b0 = (long)tb * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    double r2[16];
+    const int rg = threadIdx.x & 15, cg = threadIdx.x >> 4;
+    double r2[4][4];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) r2[k] = 0.0;
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) r2[c][r] = 0.0;
     for (int c0 = 0; c0 < dpad; c0 += DCH) {
         const int cw = min(DCH, dpad - c0);
         __syncthreads();
         stage(sa, sb, Xt1, ld1, p, a0, Xt2, ld2, q, b0, c0, cw, dpad);
         __syncthreads();
-        for (int i = 0; i < cw; ++i) {
-            const double xa = sa[i][tx];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const double t = xa - sb[i][ty * 16 + k];
-                r2[k] = fma(t, t, r2[k]);
-            }
-        }
+        patch_r2(sa, sb, cw, rg, cg, r2);
     }
-    const long a = a0 + tx;
-    if (a < p) {
+    const long a = a0 + 4 * rg;
+    const bool full = vec && a0 + 64 <= p && b0 + 64 <= q;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const long b = b0 + ty * 16 + k;
-            if (b < q) {
-                double v = sf2 * exp(-0.5 * r2[k]);
-                if (a == b) v += diag_add;
-                out[a + b * ldo] = v;
-            }
+    for (int c = 0; c < 4; ++c) {
+        const long b = b0 + 4 * cg + c;
+        double v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = sf2 * exp(-0.5 * r2[c][r]);
+            if (a + r == b) v[r] += diag_add;
+        }
+        if (full) {
+            double* o = out + a + b * ldo;
+            *reinterpret_cast<v2d*>(o) = (v2d){v[0], v[1]};
+            *reinterpret_cast<v2d*>(o + 2) = (v2d){v[2], v[3]};
+        } else if (b < q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (a + r < p) out[a + r + b * ldo] = v[r];
         }
     }
 }
 
 template <int DC>
 __global__ __launch_bounds__(256) void pair_trace_kernel(const TraceArgs g) {
-    __shared__ double sa[DCH][64], sb[DCH][64];
+    __shared__ __attribute__((aligned(16))) double sa[DCH][64], sb[DCH][64];
     __shared__ double red[4][DC + 2];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int rg = threadIdx.x & 15, cg = threadIdx.x >> 4;
     double acc[DC];
 #pragma unroll
     for (int i = 0; i < DC; ++i) acc[i] = 0.0;
@@ -112,45 +138,71 @@ __global__ __launch_bounds__(256) void pair_trace_kernel(const TraceArgs g) {
         int ta, tb;
         decode_tile(tile, g.sym != 0, g.tiles_p, ta, tb);
         const long a0 = (long)ta * 64, b0 = (long)tb * 64;
-        double r2[16];
+        double r2[4][4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) r2[k] = 0.0;
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) r2[c][r] = 0.0;
         for (int c0 = 0; c0 < g.dpad; c0 += DCH) {
             const int cw = min(DCH, g.dpad - c0);
             __syncthreads();
             stage(sa, sb, g.Xt1, g.ld1, g.p, a0, g.Xt2, g.ld2, g.q, b0, c0, cw, g.dpad);
             __syncthreads();
-            for (int i = 0; i < cw; ++i) {
-                const double xa = sa[i][tx];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const double t = xa - sb[i][ty * 16 + k];
-                    r2[k] = fma(t, t, r2[k]);
-                }
-            }
+            patch_r2(sa, sb, cw, rg, cg, r2);
         }
         // weights times K
-        const long a = a0 + tx;
-        const bool ain = a < g.p;
-        const double c1a = (ain && g.c1) ? g.c1[a] : 1.0;
-        const double c2a = (ain && g.c2) ? g.c2[a] : 1.0;
-        const double ua = (ain && g.u) ? g.u[a] : 0.0;
+        const long a = a0 + 4 * rg;
+        // tiles on the index diagonal go element by element: tr(w), and in symmetric mode the mirrored reads
+        const bool full = g.vec && ta != tb && a0 + 64 <= g.p && b0 + 64 <= g.q;
         const double symw = (g.sym && ta != tb) ? 2.0 : 1.0;
-        double qk[16];
+        double c1a[4], c2a[4], ua[4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const long b = b0 + ty * 16 + k;
-            double w = 0.0;
-            if (ain && b < g.q) {
-                // in symmetric mode only the lower triangle of M1 is valid
-                const long ia = (g.sym && a < b) ? b : a, ib = (g.sym && a < b) ? a : b;
-                w = c1a * g.M1[ia + ib * g.ldm1];
-                if (g.M2) w += c2a * g.M2[a + b * g.ldm2];
-                if (g.u) w += ua * g.v[b];
-                if (a == b) tr += w;
+        for (int r = 0; r < 4; ++r) {
+            const bool ain = a + r < g.p;
+            c1a[r] = (ain && g.c1) ? g.c1[a + r] : 1.0;
+            c2a[r] = (ain && g.c2) ? g.c2[a + r] : 1.0;
+            ua[r] = (ain && g.u) ? g.u[a + r] : 0.0;
+        }
+        double qk[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long b = b0 + 4 * cg + c;
+            double w[4] = {0.0, 0.0, 0.0, 0.0};
+            if (full) {
+                const double* m1 = g.M1 + a + b * g.ldm1;
+                const v2d x01 = *reinterpret_cast<const v2d*>(m1), x23 = *reinterpret_cast<const v2d*>(m1 + 2);
+                w[0] = c1a[0] * x01.x; w[1] = c1a[1] * x01.y; w[2] = c1a[2] * x23.x; w[3] = c1a[3] * x23.y;
+                if (g.M2) {
+                    const double* m2 = g.M2 + a + b * g.ldm2;
+                    const v2d y01 = *reinterpret_cast<const v2d*>(m2), y23 = *reinterpret_cast<const v2d*>(m2 + 2);
+                    w[0] = fma(c2a[0], y01.x, w[0]); w[1] = fma(c2a[1], y01.y, w[1]);
+                    w[2] = fma(c2a[2], y23.x, w[2]); w[3] = fma(c2a[3], y23.y, w[3]);
+                }
+                if (g.u) {
+                    const double vb = g.v[b];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[r] = fma(ua[r], vb, w[r]);
+                }
+            } else if (b < g.q) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long ar = a + r;
+                    if (ar < g.p) {
+                        // in symmetric mode only the lower triangle of M1 is valid
+                        const long ia = (g.sym && ar < b) ? b : ar, ib = (g.sym && ar < b) ? ar : b;
+                        double x = c1a[r] * g.M1[ia + ib * g.ldm1];
+                        if (g.M2) x += c2a[r] * g.M2[ar + b * g.ldm2];
+                        if (g.u) x += ua[r] * g.v[b];
+                        if (ar == b) tr += x;
+                        w[r] = x;
+                    }
+                }
             }
-            qk[k] = symw * w * (g.sf2 * exp(-0.5 * r2[k]));
-            sK += qk[k];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                qk[c][r] = symw * w[r] * (g.sf2 * exp(-0.5 * r2[c][r]));
+                sK += qk[c][r];
+            }
         }
         // per-dimension sums for dims [dim0, dim0+DC)
         if (!single) {
@@ -160,17 +212,22 @@ __global__ __launch_bounds__(256) void pair_trace_kernel(const TraceArgs g) {
         }
 #pragma unroll
         for (int i = 0; i < DC; ++i) {
-            const double xa = sa[i][tx];
+            const v2d a01 = *reinterpret_cast<const v2d*>(&sa[i][4 * rg]), a23 = *reinterpret_cast<const v2d*>(&sa[i][4 * rg + 2]);
+            const v2d b01 = *reinterpret_cast<const v2d*>(&sb[i][4 * cg]), b23 = *reinterpret_cast<const v2d*>(&sb[i][4 * cg + 2]);
+            const double xa[4] = {a01.x, a01.y, a23.x, a23.y}, xb[4] = {b01.x, b01.y, b23.x, b23.y};
             double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const double t = xa - sb[i][ty * 16 + k];
-                s = fma(qk[k], t * t, s);
-            }
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double t = xa[r] - xb[c];
+                    s = fma(qk[c][r], t * t, s);
+                }
             acc[i] += s;
         }
     }
     // block reduction -> one partial row per workgroup
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     auto wave_sum = [](double v) {
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         return v;
@@ -234,8 +291,9 @@ int gpx_cov_build(hipStream_t st, const double* Xt1, long ld1, long p, const dou
     const long tp = (p + 63) / 64, tq = (q + 63) / 64;
     const long ntiles = lower ? tp * (tp + 1) / 2 : tp * tq;
     if (ntiles > 0x7fffffffL) return GPX_ERR_ARG;
+    const int vec = ((reinterpret_cast<uintptr_t>(out) & 15) == 0 && ldo % 2 == 0) ? 1 : 0;
     hipLaunchKernelGGL(cov_build_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, Xt1, ld1, p, Xt2, ld2, q,
-                       dpad, sf2, out, ldo, lower, (int)tp, diag_add);
+                       dpad, sf2, out, ldo, lower, (int)tp, diag_add, vec);
     HIP_TRY(hipGetLastError());
     return GPX_OK;
 }
@@ -249,6 +307,8 @@ int gpx_pair_trace(hipStream_t st, TraceArgs g, int d, double* partial_ws, long 
     g.ntiles = (int)ntiles;
     g.tiles_p = (int)tp;
     g.partial = partial_ws;
+    g.vec = ((reinterpret_cast<uintptr_t>(g.M1) & 15) == 0 && g.ldm1 % 2 == 0 &&
+             (!g.M2 || ((reinterpret_cast<uintptr_t>(g.M2) & 15) == 0 && g.ldm2 % 2 == 0))) ? 1 : 0;
     const int dc = g.dpad <= 8 ? 8 : g.dpad <= 16 ? 16 : g.dpad <= 24 ? 24 : 32;
     const int width = dc + 2;
     long nwg = ntiles < 2048 ? ntiles : 2048;
