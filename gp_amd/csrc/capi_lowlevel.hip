@@ -53,6 +53,15 @@ int gpx_dgemm_splitk(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, double
                            work_doubles);
 }
 
+int gpx_dgemm_kscale(int b_kc, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                     const double* kscale, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
+                     int flags, double* work, int64_t work_doubles) {
+    if (!A || !B || !C || !kscale || M < 0 || N < 0 || K < 0) return GPX_ERR_ARG;
+    if (lda < K || ldb < (b_kc ? K : N) || ldc < M) return GPX_ERR_ARG;
+    return gpx_gemm_splitk(0, 1, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, work, work_doubles,
+                           kscale);
+}
+
 /* measurement hooks */
 int gpx_prof_gemm_begin(double min_flops, int max_launches) { return gpx_gemm_prof_begin(min_flops, max_launches); }
 int gpx_prof_gemm_end(double* total_ms, double* total_flops, int64_t* launches, double* skipped_flops) {

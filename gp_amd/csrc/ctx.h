@@ -46,7 +46,7 @@ struct gpx_ctx {
     int* info = nullptr;
     double* host_scal = nullptr;  // pinned
     // sparse workspaces (sparse.hip)
-    DevBuf Kxu, V, Bm, Cm, Kuu, Lu, Am, LA, Winv_u, Winv_A, Kuu_inv, A_inv, Wuu, Tm, Wd_u, Wd_A;
+    DevBuf Kxu, V, Bm, Cm, Kuu, Lu, Am, LA, Winv_u, Winv_A, Kuu_inv, A_inv, Wuu, Wd_u, Wd_A;
     DevBuf vn[8], vm[8], red;
     // all-reduce hook for row-sharded FITC/VFE
     gpx_allreduce_fn allreduce = nullptr;

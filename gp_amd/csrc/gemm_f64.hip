@@ -29,6 +29,7 @@ struct GemmArgs {
     int splitk;
     long slab;     // doubles between split-K slabs
     int fastA, fastB;  // base pointer and ld allow 16-B vector loads
+    const double* kscale;  // optional: op(A)(m,k) is multiplied by kscale[k] on its way to LDS (K-contiguous A only)
     int xcd_rows;      // tall-skinny outputs: the N tiles of one M tile run on ONE XCD (see kernel)
 };
 
@@ -189,7 +190,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_kernel(const GemmArgs g) {
         for (int i = 0; i < NLA; ++i) ra[i] = *reinterpret_cast<const v2d*>(pa + i * ia + ta);
 #pragma unroll
         for (int i = 0; i < NLB; ++i) rb[i] = *reinterpret_cast<const v2d*>(pb + i * ib + tb);
+        // a K-contiguous thread holds the same two k for all its loads: one 16-B scale load per tile
+        const bool scaled = AKC && g.kscale != nullptr;
+        const double* ps = scaled ? g.kscale + k00 + 2 * (tid & 7) : nullptr;
+        v2d rs = (v2d){1.0, 1.0};
+        if (scaled) rs = *reinterpret_cast<const v2d*>(ps);
         for (int kt = kt0; kt < kt1; ++kt) {
+            if (scaled) {
+#pragma unroll
+                for (int i = 0; i < NLA; ++i) ra[i] = ra[i] * rs;
+            }
             __syncthreads();
             sstore<BM, AKC, NT>(sA, ra);
             sstore<BN, BKC, NT>(sB, rb);
@@ -201,6 +211,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_kernel(const GemmArgs g) {
                 for (int i = 0; i < NLA; ++i) ra[i] = *reinterpret_cast<const v2d*>(pa + i * ia + ta);
 #pragma unroll
                 for (int i = 0; i < NLB; ++i) rb[i] = *reinterpret_cast<const v2d*>(pb + i * ib + tb);
+                if (scaled) {
+                    ps += BK;
+                    rs = *reinterpret_cast<const v2d*>(ps);
+                }
             }
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
@@ -217,11 +231,19 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_kernel(const GemmArgs g) {
             }
         }
     } else {
+        const bool scaled = AKC && g.kscale != nullptr;
+        auto scale_tile = [&](int k0) {
+            const int k = k0 + 2 * (tid & 7);
+            const v2d rs = (v2d){k < g.K ? g.kscale[k] : 0.0, k + 1 < g.K ? g.kscale[k + 1] : 0.0};
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) ra[i] = ra[i] * rs;
+        };
         if (kt0 < kt1) {
             const int k0 = klo + kt0 * BK;
             const bool kin = k0 + BK <= g.K;
             gload<BM, AKC, NT>(g.A, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
             gload<BN, BKC, NT>(g.B, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
+            if (scaled) scale_tile(k0);
         }
         for (int kt = kt0; kt < kt1; ++kt) {
             __syncthreads();
@@ -233,6 +255,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_kernel(const GemmArgs g) {
                 const bool kin = k0 + BK <= g.K;
                 gload<BM, AKC, NT>(g.A, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
                 gload<BN, BKC, NT>(g.B, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
+                if (scaled) scale_tile(k0);
             }
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
@@ -342,8 +365,9 @@ double useful_flops(long M, long N, long K, int flags) {
 
 int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
               const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
-              int flags, int splitk, double* work) {
+              int flags, int splitk, double* work, const double* kscale = nullptr) {
     if (M <= 0 || N <= 0) return GPX_OK;
+    if (kscale && (!a_kc || (reinterpret_cast<uintptr_t>(kscale) & 15))) return GPX_ERR_ARG;
     if (M > 0x7fffffffL - 256 || N > 0x7fffffffL - 256 || K > 0x7fffffffL - 256) return GPX_ERR_ARG;
     if ((flags & GEMM_LOWER) && M != N) return GPX_ERR_ARG;
     // K ranges that grow with the tile index: walk the tiles backwards so the long ones start first
@@ -354,6 +378,7 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
     g.alpha = alpha; g.beta = beta;
     g.flags = flags;
+    g.kscale = kscale;
     g.fastA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 2 == 0);
     g.fastB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 2 == 0);
     // tile choice: 128x128 when that still fills the chip, 64x64 otherwise
@@ -484,7 +509,7 @@ int gpx_gemm(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double 
 
 int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
                     const double* A, long lda, const double* B, long ldb, double beta, double* C,
-                    long ldc, int flags, double* work, long work_doubles) {
+                    long ldc, int flags, double* work, long work_doubles, const double* kscale) {
     int splitk = 1;
     if (work) {
         const long kt = (K + BK - 1) / BK;
@@ -504,5 +529,5 @@ int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, 
                 splitk *= 2;
         }
     }
-    return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, splitk, work);
+    return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, splitk, work, kscale);
 }

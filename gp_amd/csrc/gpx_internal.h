@@ -56,9 +56,11 @@ int gpx_gemm(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double 
              int flags);
 // split-K variant for short-and-wide outputs (K >> M,N): partial slabs in `work`
 // (>= splitk*M*N doubles), then a deterministic reduction.  work may be NULL -> plain gemm.
+// kscale (optional, K-contiguous A only, 16-B aligned): C = alpha * op(A) diag(kscale) op(B)^T + beta*C,
+// the weighted Gram products K^T diag(g) K of the sparse models without a scaled copy of K.
 int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
                     const double* A, long lda, const double* B, long ldb, double beta, double* C,
-                    long ldc, int flags, double* work, long work_doubles);
+                    long ldc, int flags, double* work, long work_doubles, const double* kscale = nullptr);
 
 // per-launch HIP-event timing of GEMM launches with >= min_flops useful flops (bench.py roofline)
 int gpx_gemm_prof_begin(double min_flops, int max_launches);

@@ -51,11 +51,11 @@ __global__ void sum_partials_kernel(const double* __restrict__ part, int nblk, d
 }
 
 // ---- FITC row kernels (one thread per training row; consecutive rows -> coalesced columns) ------
-// Gamma, 1/Gamma, p = r/Gamma, Ksc = diag(1/Gamma) Kxu   (FITC.cpp:215-216, 253-254)
+// Gamma, 1/Gamma, p = r/Gamma   (FITC.cpp:215-216, 253-254); diag(1/Gamma) Kxu is never formed: the
+// Gram products take 1/Gamma as the K-dimension scale of the GEMM and C is scaled per row where it is used
 __global__ __launch_bounds__(256) void fitc_gamma_kernel(long n, long m, const double* __restrict__ V, long ld,
-                                                         const double* __restrict__ Kxu, const double* __restrict__ r,
-                                                         double sn2, double sf2, double* __restrict__ g,
-                                                         double* __restrict__ p, double* __restrict__ Ksc,
+                                                         const double* __restrict__ r, double sn2, double sf2,
+                                                         double* __restrict__ g, double* __restrict__ p,
                                                          double* __restrict__ part) {
     const long a = (long)blockIdx.x * 256 + threadIdx.x;
     double v[PW] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -72,7 +72,6 @@ __global__ __launch_bounds__(256) void fitc_gamma_kernel(long n, long m, const d
         const double ig = 1.0 / Gam;
         g[a] = ig;
         p[a] = ig * r[a];
-        for (b = 0; b < m; ++b) Ksc[a + b * ld] = Kxu[a + b * ld] * ig;
         v[0] = log(Gam);
         v[1] = r[a] * (ig * r[a]);
         v[2] = 1.0;
@@ -80,9 +79,10 @@ __global__ __launch_bounds__(256) void fitc_gamma_kernel(long n, long m, const d
     block_partials(v, part);
 }
 
-// c1 = rowsum(C o Ksc), q, pq = p - q, w and the trace coefficients; Bw = diag(w) B
-__global__ __launch_bounds__(256) void fitc_rowstats_kernel(long n, long m, const double* __restrict__ Cm,
-                                                            const double* __restrict__ Ksc, long ld,
+// With Cu = Kxu A^-1 (C = diag(g) Cu): c1 = rowsum(C o diag(g) Kxu) = g^2 rowsum(Cu o Kxu), q, pq = p - q,
+// w and the trace coefficients
+__global__ __launch_bounds__(256) void fitc_rowstats_kernel(long n, long m, const double* __restrict__ Cu,
+                                                            const double* __restrict__ Kxu, long ld,
                                                             const double* __restrict__ Ka, const double* __restrict__ g,
                                                             const double* __restrict__ p, double sn2,
                                                             double* __restrict__ c2coef, double* __restrict__ ucoef,
@@ -93,11 +93,11 @@ __global__ __launch_bounds__(256) void fitc_rowstats_kernel(long n, long m, cons
         double s0 = 0.0, s1 = 0.0;
         long b = 0;
         for (; b + 1 < m; b += 2) {
-            s0 = fma(Cm[a + b * ld], Ksc[a + b * ld], s0);
-            s1 = fma(Cm[a + (b + 1) * ld], Ksc[a + (b + 1) * ld], s1);
+            s0 = fma(Cu[a + b * ld], Kxu[a + b * ld], s0);
+            s1 = fma(Cu[a + (b + 1) * ld], Kxu[a + (b + 1) * ld], s1);
         }
-        if (b < m) s0 = fma(Cm[a + b * ld], Ksc[a + b * ld], s0);
-        const double c1 = s0 + s1;
+        if (b < m) s0 = fma(Cu[a + b * ld], Kxu[a + b * ld], s0);
+        const double c1 = g[a] * g[a] * (s0 + s1);
         const double q = g[a] * Ka[a];
         const double pq = p[a] - q;
         const double w = g[a] - c1 - pq * pq / sn2;
@@ -110,14 +110,6 @@ __global__ __launch_bounds__(256) void fitc_rowstats_kernel(long n, long m, cons
         v[3] = w;
     }
     block_partials(v, part);
-}
-
-__global__ __launch_bounds__(256) void rowscale_kernel(long n, long m, const double* __restrict__ in, long ld,
-                                                       const double* __restrict__ s, double* __restrict__ out) {
-    const long a = (long)blockIdx.x * 256 + threadIdx.x;
-    if (a >= n) return;
-    const double sa = s[a];
-    for (long b = 0; b < m; ++b) out[a + b * ld] = in[a + b * ld] * sa;
 }
 
 // alpha = (r - Ka)/sn2 (VFE.cpp:183) and its negation; partials: alpha^2, alpha, r^2 not needed here
@@ -231,8 +223,8 @@ struct Sparse {
         const long nm = ldn * m, mm = ldm * m;
         if ((rc = c->Kxu.ensure(nm))) return rc;
         if (model == GPX_MODEL_FITC) {
-            if ((rc = c->V.ensure(nm)) || (rc = c->Cm.ensure(nm))) return rc;  // Cm doubles as Ksc
-            if (grad && ((rc = c->Bm.ensure(nm)) || (rc = c->Tm.ensure(nm)))) return rc;
+            if ((rc = c->V.ensure(nm))) return rc;
+            if (grad && ((rc = c->Bm.ensure(nm)) || (rc = c->Cm.ensure(nm)))) return rc;
         } else if (grad) {
             if ((rc = c->Cm.ensure(nm))) return rc;
         }
@@ -343,7 +335,6 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     double* g = c->vn[0].p;   // 1/Gamma
     double* p = c->vn[1].p;   // r/Gamma
     double* Ka = c->vn[2].p;
-    double* Ksc = c->Cm.p;    // FITC: diag(1/Gamma) Kxu, later reused
     double* hs = c->host_scal;
     *nll = INF;
     if (calc_grad) memset(grad, 0, sizeof(double) * nh);  // FITC.cpp:232 / VFE.cpp:194 on failure
@@ -351,13 +342,12 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     // ---- phase 1 ------------------------------------------------------------------------------
     if ((rc = s.kernels(jitter, true, true))) return rc;  // Lu diag + Winv_u = Lu^-1
     HIP_TRY(hipMemsetAsync(redT, 0, 16 * sizeof(double), st));
-    const double* Sop = fitc ? Ksc : c->Kxu.p;
     if (fitc) {
         // V = Kxu Lu^-T (FITC.cpp:213-215 via the factor: diag(Kxu Kuu^-1 Kux) = rowsum(V o V))
         if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->Winv_u.p, ldm, 0.0, c->V.p, ldn, GEMM_KHI_N)))
             return rc;
-        hipLaunchKernelGGL(fitc_gamma_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, c->V.p, ldn, c->Kxu.p, c->r.p, h.sn2,
-                           h.sf2, g, p, Ksc, s.part());
+        hipLaunchKernelGGL(fitc_gamma_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, c->V.p, ldn, c->r.p, h.sn2, h.sf2, g,
+                           p, s.part());
         s.finish_partials(n, redT, 3);  // sum log Gamma, r^T Gamma^-1 r, n_local
         if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, p, 0.0, redF))) return rc;  // F = Kux Gamma^-1 r
     } else {
@@ -366,7 +356,8 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, c->r.p, 0.0, redF))) return rc;  // F = Kux r
     }
     // S = Kux [Gamma^-1] Kxu, lower tiles, split-K over the training rows (FITC.cpp:217, VFE.cpp:173)
-    if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, Sop, ldn, c->Kxu.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap)))
+    if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Kxu.p, ldn, c->Kxu.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
+                              fitc ? g : nullptr)))
         return rc;
     HIP_TRY(hipEventRecord(c->ev[0], st));
     if (fitc && calc_grad) {
@@ -441,22 +432,22 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     if (fitc) {
         if ((rc = s.gram(c->Winv_u.p, c->Kuu_inv.p))) return rc;
         // C = Gamma^-1 Kxu A^-1 (FITC.cpp:262) and B = Kxu Kuu^-1 = V Lu^-1 (FITC.cpp:214)
-        double* Cm = c->Tm.p;
-        if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, Ksc, ldn, c->A_inv.p, ldm, 0.0, Cm, ldn, 0))) return rc;
+        double* Cm = c->Cm.p;  // Cu = Kxu A^-1; C = diag(1/Gamma) Cu enters through per-row coefficients
+        if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->A_inv.p, ldm, 0.0, Cm, ldn, 0))) return rc;
         double* c2coef = c->vn[3].p;
         double* ucoef = c->vn[4].p;
         double* wv = c->vn[5].p;
-        hipLaunchKernelGGL(fitc_rowstats_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, Cm, Ksc, ldn, Ka, g, p, h.sn2,
+        hipLaunchKernelGGL(fitc_rowstats_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, Cm, c->Kxu.p, ldn, Ka, g, p, h.sn2,
                            c2coef, ucoef, wv, s.part());
         s.finish_partials(n, redT + GPX_MAX_DIM + 8, 4);  // sum(g-c1), sum pq^2, sum pq, sum w
         // half of W_xu = C - (1/sn2) pq a^T - (1/sn2) diag(w) B, contracted with every dKxu at once
-        ta.M1 = Cm; ta.ldm1 = ldn;
+        ta.M1 = Cm; ta.ldm1 = ldn; ta.c1 = g;
         ta.M2 = c->Bm.p; ta.ldm2 = ldn; ta.c2 = c2coef;
         ta.u = ucoef;
         if ((rc = gpx_pair_trace(st, ta, d, c->trace_ws.p, c->trace_ws.cap, redT))) return rc;
-        // B^T diag(w) B (signed weights: scaled copy, then the lower-tile split-K product)
-        hipLaunchKernelGGL(rowscale_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, c->Bm.p, ldn, wv, Ksc);
-        if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, Ksc, ldn, c->Bm.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap)))
+        // B^T diag(w) B: w (signed) is the K-dimension scale of the lower-tile split-K product
+        if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Bm.p, ldn, c->Bm.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
+                                  wv)))
             return rc;
         if ((rc = s.allreduce(red, m * m + m + GPX_MAX_DIM + 32))) return rc;
         hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, red, m);
@@ -557,11 +548,11 @@ int gpx_sparse_prepare(gpx_ctx* c, int model, int cov, const double* hyp, double
             if ((rc = s.inverse(c->Lu.p, c->Wd_u.p, c->Winv_u.p, nullptr, true))) return rc;
             if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->Winv_u.p, ldm, 0.0, c->V.p, ldn, GEMM_KHI_N)))
                 return rc;
-            hipLaunchKernelGGL(fitc_gamma_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, c->V.p, ldn, c->Kxu.p, c->r.p,
-                               h.sn2, h.sf2, c->vn[0].p, c->vn[1].p, c->Cm.p, s.part());
+            hipLaunchKernelGGL(fitc_gamma_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, c->V.p, ldn, c->r.p, h.sn2, h.sf2,
+                               c->vn[0].p, c->vn[1].p, s.part());
             if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, c->vn[1].p, 0.0, redF))) return rc;
-            if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Cm.p, ldn, c->Kxu.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p,
-                                      c->T.cap)))
+            if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Kxu.p, ldn, c->Kxu.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p,
+                                      c->T.cap, c->vn[0].p)))
                 return rc;
         } else {
             if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, c->r.p, 0.0, redF))) return rc;

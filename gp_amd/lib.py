@@ -41,6 +41,7 @@ lib.gpx_set_device.argtypes = [_i]
 lib.gpx_device_count.argtypes = [C.POINTER(_i)]
 lib.gpx_dgemm.argtypes = [_i, _i, _i64, _i64, _i64, _d, _vp, _i64, _vp, _i64, _d, _vp, _i64, _i]
 lib.gpx_dgemm_splitk.argtypes = lib.gpx_dgemm.argtypes + [_vp, _i64]
+lib.gpx_dgemm_kscale.argtypes = [_i, _i64, _i64, _i64, _d, _vp, _i64, _vp, _vp, _i64, _d, _vp, _i64, _i, _vp, _i64]
 
 
 def device_count():
@@ -90,7 +91,7 @@ def colmajor(a):
     return np.asfortranarray(a, dtype=np.float64).ravel(order="K")
 
 
-def dgemm(A, B, C_in=None, a_kc=False, b_kc=False, alpha=1.0, beta=0.0, flags=0, splitk_work=0):
+def dgemm(A, B, C_in=None, a_kc=False, b_kc=False, alpha=1.0, beta=0.0, flags=0, splitk_work=0, kscale=None):
     """Test helper: A is (M, K), B is (N, K) as NumPy arrays; computes alpha*A@B.T + beta*C on the GPU.
     a_kc / b_kc choose the device storage of the operand (K-contiguous or M/N-contiguous)."""
     A = np.asarray(A, dtype=np.float64)
@@ -103,7 +104,13 @@ def dgemm(A, B, C_in=None, a_kc=False, b_kc=False, alpha=1.0, beta=0.0, flags=0,
     dC = DeviceBuffer.from_numpy(colmajor(Cm))
     lda = K if a_kc else M
     ldb = K if b_kc else N
-    if splitk_work:
+    if kscale is not None:
+        assert a_kc, "kscale needs a K-contiguous A"
+        ds = DeviceBuffer.from_numpy(np.ascontiguousarray(kscale, dtype=np.float64))
+        w = DeviceBuffer(splitk_work) if splitk_work else None
+        check(lib.gpx_dgemm_kscale(int(b_kc), M, N, K, alpha, dA.ptr, lda, ds.ptr, dB.ptr, ldb, beta, dC.ptr, M, flags,
+                                   w.ptr if w else None, splitk_work), "dgemm_kscale")
+    elif splitk_work:
         w = DeviceBuffer(splitk_work)
         check(lib.gpx_dgemm_splitk(int(a_kc), int(b_kc), M, N, K, alpha, dA.ptr, lda, dB.ptr, ldb, beta,
                                    dC.ptr, M, flags, w.ptr, splitk_work), "dgemm_splitk")

@@ -32,6 +32,12 @@ int gpx_dgemm(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, double alpha,
 int gpx_dgemm_splitk(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
                      int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
                      int flags, double* work, int64_t work_doubles);
+/* C = alpha * A^T diag(kscale) B' + beta*C with A stored K-contiguous (K x M, column stride lda): the
+ * weighted Gram products Kux Gamma^-1 Kxu (FITC.cpp:217) and B^T diag(w) B (FITC.cpp:276-290 summed
+ * over the hypers) without forming the row-scaled n x m copy the reference builds. */
+int gpx_dgemm_kscale(int b_kc, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                     const double* kscale, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
+                     int flags, double* work, int64_t work_doubles);
 
 
 /* ---- measurement hooks (no reference counterpart) ------------------------------------------ */

@@ -70,3 +70,23 @@ def test_gemm_splitk_tall():
     D = rng.uniform(-1, 1, (M, K))
     C = lib.dgemm(D, D, a_kc=True, b_kc=True, flags=lib.GEMM_LOWER, splitk_work=64 * M * M)
     assert np.max(np.abs(np.tril(C) - np.tril(D @ D.T))) < 1e-10
+
+
+@pytest.mark.parametrize("shape", [(96, 160, 40000), (1024, 1024, 8192), (130, 70, 1000)])
+def test_gemm_kscale_weighted_gram(shape):
+    """A^T diag(s) B with signed weights, the K-dimension scale applied on the way to LDS (interior
+    and edge tiles, with and without split-K): the FITC products Kux Gamma^-1 Kxu and B^T diag(w) B."""
+    lib = _lib()
+    M, N, K = shape
+    rng = np.random.default_rng(M + K)
+    A = rng.uniform(-1, 1, (M, K))
+    B = rng.uniform(-1, 1, (N, K))
+    s = rng.normal(size=K)
+    ref = (A * s) @ B.T
+    C = lib.dgemm(A, B, a_kc=True, b_kc=True, kscale=s)
+    assert np.max(np.abs(C - ref)) < 1e-11 * K ** 0.5 * 10
+    C = lib.dgemm(A, B, a_kc=True, b_kc=True, kscale=s, splitk_work=64 * M * N)
+    assert np.max(np.abs(C - ref)) < 1e-11 * K ** 0.5 * 10
+    if M == N:
+        C = lib.dgemm(A, A, a_kc=True, b_kc=True, kscale=s, flags=lib.GEMM_LOWER, splitk_work=64 * M * N)
+        assert np.max(np.abs(np.tril(C) - np.tril((A * s) @ A.T))) < 1e-11 * K ** 0.5 * 10
