@@ -24,9 +24,9 @@ int gpx_scale_inputs(hipStream_t st, const double* X, long n, int d, int dpad, c
                      double* Xt, long ldx);
 int gpx_cov_build(hipStream_t st, const double* Xt1, long ld1, long p, const double* Xt2, long ld2, long q,
                   int dpad, double sf2, double* out, long ldo, int lower, double diag_add);
-// out[0..d-1] = S_i, out[d] = sum w K, out[d+1] = tr(w); partial_ws >= 2048*34 doubles
+// out[0..d-1] = S_i, out[d] = sum w K, out[d+1] = tr(w); partial_ws >= 2048*66 doubles
 int gpx_pair_trace(hipStream_t st, TraceArgs g, int d, double* partial_ws, long ws_doubles, double* out);
-#define GPX_TRACE_WS (2048L * 34)
+#define GPX_TRACE_WS (2048L * 66)
 
 // ---- chol.hip -------------------------------------------------------------------------------
 // Blocked recursive lower Cholesky in place (lower triangle of A).  Wd (64 x roundup(n,64),

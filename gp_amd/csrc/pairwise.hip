@@ -14,6 +14,7 @@
 // first index so every global access is a contiguous 512-B row per wave.
 #include "gpx_internal.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -204,27 +205,33 @@ __global__ __launch_bounds__(256) void pair_trace_kernel(const TraceArgs g) {
                 sK += qk[c][r];
             }
         }
-        // per-dimension sums for dims [dim0, dim0+DC)
-        if (!single) {
-            __syncthreads();
-            stage(sa, sb, g.Xt1, g.ld1, g.p, a0, g.Xt2, g.ld2, g.q, b0, g.dim0, DC, g.dpad);
-            __syncthreads();
-        }
+        // per-dimension sums for dims [dim0, dim0+DC), DCH dimensions in LDS at a time
+        auto dims_chunk = [&](auto ch_tag) {
+            constexpr int ch = decltype(ch_tag)::value;
+            constexpr int cw = DC - ch * DCH < DCH ? DC - ch * DCH : DCH;
+            if (!single) {
+                __syncthreads();
+                stage(sa, sb, g.Xt1, g.ld1, g.p, a0, g.Xt2, g.ld2, g.q, b0, g.dim0 + ch * DCH, cw, g.dpad);
+                __syncthreads();
+            }
 #pragma unroll
-        for (int i = 0; i < DC; ++i) {
-            const v2d a01 = *reinterpret_cast<const v2d*>(&sa[i][4 * rg]), a23 = *reinterpret_cast<const v2d*>(&sa[i][4 * rg + 2]);
-            const v2d b01 = *reinterpret_cast<const v2d*>(&sb[i][4 * cg]), b23 = *reinterpret_cast<const v2d*>(&sb[i][4 * cg + 2]);
-            const double xa[4] = {a01.x, a01.y, a23.x, a23.y}, xb[4] = {b01.x, b01.y, b23.x, b23.y};
-            double s = 0.0;
+            for (int i = 0; i < cw; ++i) {
+                const v2d a01 = *reinterpret_cast<const v2d*>(&sa[i][4 * rg]), a23 = *reinterpret_cast<const v2d*>(&sa[i][4 * rg + 2]);
+                const v2d b01 = *reinterpret_cast<const v2d*>(&sb[i][4 * cg]), b23 = *reinterpret_cast<const v2d*>(&sb[i][4 * cg + 2]);
+                const double xa[4] = {a01.x, a01.y, a23.x, a23.y}, xb[4] = {b01.x, b01.y, b23.x, b23.y};
+                double s = 0.0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double t = xa[r] - xb[c];
-                    s = fma(qk[c][r], t * t, s);
-                }
-            acc[i] += s;
-        }
+                    for (int r = 0; r < 4; ++r) {
+                        const double t = xa[r] - xb[c];
+                        s = fma(qk[c][r], t * t, s);
+                    }
+                acc[ch * DCH + i] += s;
+            }
+        };
+        dims_chunk(std::integral_constant<int, 0>{});
+        if constexpr (DC > DCH) dims_chunk(std::integral_constant<int, 1>{});
     }
     // block reduction -> one partial row per workgroup
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -309,6 +316,7 @@ int gpx_pair_trace(hipStream_t st, TraceArgs g, int d, double* partial_ws, long 
     g.partial = partial_ws;
     g.vec = ((reinterpret_cast<uintptr_t>(g.M1) & 15) == 0 && g.ldm1 % 2 == 0 &&
              (!g.M2 || ((reinterpret_cast<uintptr_t>(g.M2) & 15) == 0 && g.ldm2 % 2 == 0))) ? 1 : 0;
+    // 32 dimensions per pass (wider accumulator sets spill: the 4x4 patch already holds r2 and w K)
     const int dc = g.dpad <= 8 ? 8 : g.dpad <= 16 ? 16 : g.dpad <= 24 ? 24 : 32;
     const int width = dc + 2;
     long nwg = ntiles < 2048 ? ntiles : 2048;
