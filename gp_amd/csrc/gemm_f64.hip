@@ -481,7 +481,9 @@ int gpx_gemm_prof_end(double* total_ms, double* total_flops, long* launches, dou
 }
 
 int gpx_mfma_peak(double* tflops) {
-    const int blocks = 256 * 8, iters = 8192;  // 8 waves per SIMD, 4 independent accumulators each
+    // 2 waves per SIMD (what the GEMM runs with), 4 independent accumulators each; with 8 waves per
+    // SIMD the same loop only keeps the pipe 63 % busy (profiles/r01_pmc)
+    const int blocks = 256 * 2, iters = 32768;
     double* out = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out), (size_t)blocks * 256 * 8));
     hipEvent_t e0, e1;
