@@ -215,7 +215,7 @@ def main():
         lib.check(lib.lib.gpx_bench_mfma_f64_peak(C.byref(peak)), "mfma_peak")
         out["measured_bare_mfma_f64_tflops"] = peak.value
         if not args.no_cpu_baseline and D.world == 1 and "exact" in want:
-            out["cpu_baseline"] = cpu_baseline_exact(args.d, 2048, args.n)
+            out["cpu_baseline"] = cpu_baseline_exact(args.d, min(4096, args.n), args.n)  # ~20 s of CPU work
         print(json.dumps(out))
     if D.dist is not None:
         D.dist.destroy_process_group()
