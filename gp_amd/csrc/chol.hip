@@ -15,17 +15,22 @@ constexpr int NB = GPX_NB0;
 constexpr int SP = NB + 1;  // padded LDS stride
 
 // Factor AND invert one nb x nb (nb <= 64, identity-padded to 64) diagonal block in ONE workgroup.
-// Right-looking elimination on the register-resident pair [S | E]: thread (tr, tc) owns the 4x4 tile
-// rows 4tr.., columns 4tc.. of both the Schur complement S and of E (initially I).  Step j needs only
-// column j of S and row j of E; their owners publish them to a double-buffered LDS vector during
-// step j-1 (look-ahead), so a step costs ONE barrier:  S_ik -= S_ij S_kj / d_j,  E_i: -= (S_ij/d_j) E_j:.
-// At the end L_ij = S_ij / sqrt(d_j) and W = L^-1 = diag(1/sqrt(d)) E.  Writes L over the lower
+// Right-looking LDL^T elimination on the register-resident pair [S | E] (E starts as I): thread
+// (tr, tc) owns the 4x4 patch rows 4tr.., columns 4tc.. of both.  The 16 panels of 4 columns cost two
+// barriers each:
+//   A  the owner of the diagonal patch eliminates it in registers (the only serial divisions) and
+//      publishes its unscaled lower entries u_kj, the multipliers m_kj = u_kj / d_j and 1/d_j;
+//   B  the patches below it finish their 4 columns (publishing u_ij, m_ij), the E patches of the panel
+//      rows apply the same 4x4 unit-lower elimination (publishing the 4 finished rows of E);
+//   C  every patch below the panel takes ONE rank-4 update: S_ik -= sum_j u_ij m_kj right of the
+//      panel, E_i: -= sum_j m_ij E_j: left of it (a patch is on one side only).
+// At the end L_ij = u_ij / sqrt(d_j) and W = L^-1 = diag(1/sqrt(d)) E.  Writes L over the lower
 // triangle of A and W (lower, zeros above) with leading dimension ldw.
 __global__ __launch_bounds__(256) void potrf_base_tile_kernel(double* __restrict__ A, long lda, int nb,
                                                               double* __restrict__ W, long ldw, int wfull,
                                                               int* __restrict__ info) {
-    __shared__ __align__(16) double colbuf[2][NB];
-    __shared__ __align__(16) double rowbuf[2][NB];
+    __shared__ __align__(16) double U11[4][4], M11[4][4], invd[4];
+    __shared__ __align__(16) double Ucol[NB][4], Mcol[NB][4], Erow[4][NB];
     __shared__ double dvec[NB];
     const int tid = threadIdx.x, tr = tid & 15, tc = tid >> 4;
     const int r0 = 4 * tr, c0 = 4 * tc;
@@ -38,58 +43,111 @@ __global__ __launch_bounds__(256) void potrf_base_tile_kernel(double* __restrict
             e[a][b] = (i == k) ? 1.0 : 0.0;
             s[a][b] = (i < nb && k < nb && k <= i) ? A[i + (long)k * lda] : e[a][b];
         }
-    if (tc == 0)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) colbuf[0][r0 + a] = s[a][0];
-    if (tr == 0)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) rowbuf[0][c0 + b] = e[0][b];
-    __syncthreads();
     bool bad = false;
-    for (int jt = 0; jt < NB / 4; ++jt) {
+    for (int p = 0; p < NB / 4; ++p) {
+        // ---- A: diagonal patch
+        if (tr == p && tc == p) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = 4 * jt + jj;
-            const double* cb = colbuf[jj & 1];
-            const double* rb = rowbuf[jj & 1];
-            const double piv = cb[j];
-            bad = bad || !(piv > 0.0);  // Eigen::LLT: NumericalIssue on a pivot <= 0
-            const double inv = 1.0 / piv;
-            double li[4], lk[4], mi[4], rj[4];
+            for (int j = 0; j < 4; ++j) {
+                const double d = s[j][j];
+                bad = bad || !(d > 0.0);  // Eigen::LLT: NumericalIssue on a pivot <= 0
+                const double inv = 1.0 / d;
+                dvec[4 * p + j] = d;
+                invd[j] = inv;
+                double m[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                li[a] = (r0 + a > j) ? cb[r0 + a] : 0.0;
-                mi[a] = li[a] * inv;
+                for (int a = j + 1; a < 4; ++a) {
+                    m[a] = s[a][j] * inv;
+                    U11[a][j] = s[a][j];
+                    M11[a][j] = m[a];
+                }
+#pragma unroll
+                for (int b = j + 1; b < 4; ++b)
+#pragma unroll
+                    for (int a = b; a < 4; ++a) s[a][b] = fma(-m[a], s[b][j], s[a][b]);
             }
+        }
+        __syncthreads();
+        // ---- B: rest of the column panel, and the panel's rows of E
+        if (tc == p && tr > p) {
+            double u[4][4], mm[4][4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                lk[b] = (c0 + b > j) ? cb[c0 + b] * inv : 0.0;
-                rj[b] = rb[c0 + b];
-            }
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int j = 0; j < 4; ++j) {
+                const double inv = invd[j];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    s[a][b] = fma(-li[a], lk[b], s[a][b]);
-                    e[a][b] = fma(-mi[a], rj[b], e[a][b]);
+                    u[a][j] = s[a][j];
+                    mm[a][j] = u[a][j] * inv;
                 }
-            if (tid == 0) dvec[j] = piv;
-            // look-ahead: publish column j+1 of S and row j+1 of E for the next step
-            const int jn = j + 1, bn = (jj + 1) & 3, tn = jn >> 2;
-            if (jn < NB) {
-                double* cbn = colbuf[(jj + 1) & 1];
-                double* rbn = rowbuf[(jj + 1) & 1];
-                if (tc == tn)
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) cbn[r0 + a] = s[a][bn];
-                if (tr == tn)
+                for (int k = j + 1; k < 4; ++k) {
+                    const double ukj = U11[k][j];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) rbn[c0 + b] = e[bn][b];
+                    for (int a = 0; a < 4; ++a) s[a][k] = fma(-mm[a][j], ukj, s[a][k]);
+                }
             }
-            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Ucol[r0 + a][j] = u[a][j];
+                    Mcol[r0 + a][j] = mm[a][j];
+                }
+        }
+        if (tr == p && tc <= p) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int a = j + 1; a < 4; ++a) {
+                    const double m = M11[a][j];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) e[a][b] = fma(-m, e[j][b], e[a][b]);
+                }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) Erow[a][c0 + b] = e[a][b];
+        }
+        __syncthreads();
+        // ---- C: one rank-4 update per patch below the panel
+        if (tr > p) {
+            if (tc > p) {
+                if (tc <= tr) {
+                    double u[4][4], mk[4][4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            u[a][j] = Ucol[r0 + a][j];
+                            mk[a][j] = Mcol[c0 + a][j];
+                        }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) s[a][b] = fma(-u[a][j], mk[b][j], s[a][b]);
+                }
+            } else {
+                double mi[4][4], er[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        mi[a][j] = Mcol[r0 + a][j];
+                        er[a][j] = Erow[a][c0 + j];  // er[j'][b]: row j' of the panel, column c0 + b
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) e[a][b] = fma(-mi[a][j], er[j][b], e[a][b]);
+            }
         }
     }
-    if (bad && tid == 0) *info = 1;
+    __syncthreads();
+    if (bad) *info = 1;
     double sc[4], sr[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) sc[b] = sqrt(dvec[c0 + b]);
