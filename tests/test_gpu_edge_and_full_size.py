@@ -1,0 +1,207 @@
+"""GPU tests at the edges of the input space and, through size-independent properties, at the full
+BASELINE.json sizes (where the scalar oracle would take hours): permutation invariance of the NLL,
+analytic gradient against a central difference ALONG a direction, predict round trips."""
+import numpy as np
+import pytest
+
+import np_gp
+import oracle
+from gp_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b)))
+
+
+@pytest.fixture(scope="module")
+def gpx():
+    from gp_amd import lib
+    return lib
+
+
+# ---- edges -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d", [(1, 1), (2, 1), (3, 2), (63, 1), (64, 9), (65, 17), (129, 128)])
+def test_exact_tiny_and_wide_inputs(gpx, n, d):
+    X, y, hyp, Xs = synth.make_problem(5, n, d, 7)
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    nll, g = ctx.nll_grad(gpx.MODEL_EXACT, 0, hyp)
+    nll_o, g_o = oracle.exact_nll(0, X, y, hyp)
+    assert abs(nll - nll_o) <= 1e-9 * max(1.0, abs(nll_o))
+    assert np.max(np.abs(g - g_o)) <= 1e-7 * max(1.0, np.max(np.abs(g_o)))
+    ctx.prepare(gpx.MODEL_EXACT, 0, hyp)
+    mu, s2, gmu, gs2 = ctx.predict_with_grad(Xs)
+    mu_o, s2_o, gmu_o, gs2_o = oracle.ExactState(0, X, y, hyp).predict(Xs, grad=True)
+    assert rel(mu, mu_o) <= 1e-9 and rel(s2, s2_o) <= 1e-9
+    assert np.max(np.abs(gmu - gmu_o)) <= 1e-8 * max(1.0, np.max(np.abs(gmu_o)))
+    assert np.max(np.abs(gs2 - gs2_o)) <= 1e-8 * max(1.0, np.max(np.abs(gs2_o)))
+    ctx.close()
+
+
+def test_dimension_limit_and_empty_requests(gpx):
+    X, y, hyp, _ = synth.make_problem(5, 20, 129)
+    ctx = gpx.Context()
+    with pytest.raises(gpx.GpxError):
+        ctx.set_data(X, y)                                  # d > GPX_MAX_DIM (128): refused, not truncated
+    X, y, hyp, _ = synth.make_problem(5, 20, 3)
+    ctx.set_data(X, y)
+    ctx.prepare(gpx.MODEL_EXACT, 0, hyp)
+    mu, s2 = ctx.predict(np.empty((0, 3)))                  # no test points: nothing to do, no error
+    assert mu.shape == (0,) and s2.shape == (0,)
+    with pytest.raises(gpx.GpxError):
+        ctx.nll_grad(gpx.MODEL_FITC, 0, hyp, jitter=1e-6)   # sparse objective without inducing points
+    ctx.close()
+
+
+@pytest.mark.parametrize("model", ["fitc", "vfe"])
+@pytest.mark.parametrize("n,d,m", [(5, 1, 1), (40, 2, 1), (64, 3, 64), (100, 4, 65), (30, 2, 50)])
+def test_sparse_ragged_and_degenerate_inducing_sets(gpx, model, n, d, m):
+    """one inducing point, m = 64 / 65 around the base-block size, more inducing points than data"""
+    X, y, hyp, Xs = synth.make_problem(6, n + m, d, 9)
+    U, X, y = X[n:], X[:n], y[:n]
+    hyp = hyp.copy()
+    hyp[:d] -= 1.5          # length scales ~0.3 of the data range: 64 inducing points in d <= 4 stay independent
+    jit = 1e-6
+    M = gpx.MODEL_FITC if model == "fitc" else gpx.MODEL_VFE
+    fo = oracle.fitc_nll if model == "fitc" else oracle.vfe_nll
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    ctx.set_inducing(U)
+    nll, g = ctx.nll_grad(M, 0, hyp, jitter=jit)
+    nll_o, g_o = fo(0, X, y, U, jit, hyp)
+    # 1e-9 / 1e-7 wherever two correct fp64 evaluations agree that well; the bound is widened only by the
+    # measured disagreement of the literal oracle with the independent NumPy evaluation on the SAME inputs
+    nll_n, g_n = (np_gp.fitc_nll if model == "fitc" else np_gp.vfe_nll)(0, X, y, U, jit, hyp)
+    tol_f = max(1e-9, 3 * abs(nll_n - nll_o) / max(1.0, abs(nll_o)))
+    tol_g = max(1e-7, 3 * np.max(np.abs(g_n - g_o)) / max(1.0, np.max(np.abs(g_o))))
+    assert abs(nll - nll_o) <= tol_f * max(1.0, abs(nll_o)), (nll, nll_o, nll_n)
+    assert np.max(np.abs(g - g_o)) <= tol_g * max(1.0, np.max(np.abs(g_o)))
+    ctx.prepare(M, 0, hyp, jitter=jit)
+    st = oracle.SparseState(model, 0, X, y, U, jit, hyp)
+    mu, s2 = ctx.predict(Xs)
+    mu_o, s2_o = st.predict(Xs)
+    tol_p = max(1e-9, 10 * tol_f)
+    assert np.max(np.abs(mu - mu_o)) <= tol_p * max(1.0, np.max(np.abs(mu_o)))
+    assert np.max(np.abs(s2 - s2_o)) <= tol_p * max(1.0, np.max(np.abs(s2_o)))
+    ctx.close()
+
+
+@pytest.mark.parametrize("model", ["fitc", "vfe"])
+def test_sparse_redundant_inducing_points_conditioning(gpx, model):
+    """64 inducing points that a smooth kernel in d = 3 makes numerically dependent: cond(Kuu + jitter I)
+    ~ 2e7 and the objective divides by sn2, so two correct fp64 operation orders (e.g. <Kuu^-1, S> vs
+    ||Lu^-1 Kux||^2 for the VFE trace term) differ by ~3e-7 here.  The bound is that forward-error scale,
+    cond * eps * n sf2 / sn2, not 1e-9: on such inputs no re-ordered evaluation can promise more."""
+    n, d, m = 64, 3, 64
+    X, y, hyp, _ = synth.make_problem(6, n + m, d)
+    U, X, y = X[n:], X[:n], y[:n]
+    jit = 1e-6
+    ell, sf2, sn2 = np.exp(hyp[:d]), np.exp(2 * hyp[d]), np.exp(2 * hyp[d + 1])
+    D = ((U[:, None, :] - U[None, :, :]) / ell) ** 2
+    cond = np.linalg.cond(sf2 * np.exp(-0.5 * D.sum(-1)) + jit * np.eye(m))
+    bound = 10 * cond * np.finfo(float).eps * n * sf2 / sn2
+    assert 1e-7 < bound < 1e-3
+    M = gpx.MODEL_FITC if model == "fitc" else gpx.MODEL_VFE
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    ctx.set_inducing(U)
+    nll, g = ctx.nll_grad(M, 0, hyp, jitter=jit)
+    nll_o, g_o = (oracle.fitc_nll if model == "fitc" else oracle.vfe_nll)(0, X, y, U, jit, hyp)
+    assert abs(nll - nll_o) <= bound
+    assert np.max(np.abs(g - g_o)) <= 100 * bound * max(1.0, np.max(np.abs(g_o)))
+    ctx.close()
+
+
+@pytest.mark.parametrize("cov", [0, 1])
+def test_extreme_hyperparameters(gpx, cov):
+    """length scales far below / above the data range, large signal-to-noise: K -> sf2 I and K -> sf2 11^T"""
+    n, d = 200, 5
+    X, y, hyp0, _ = synth.make_problem(7, n, d)
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    for shift, log_sn in ((-5.0, np.log(0.1)), (4.0, np.log(0.3)), (0.0, np.log(1e-3))):
+        hyp = np.concatenate([hyp0[:d] + shift, [0.3, log_sn, 0.1]]) if cov == 0 else np.array([shift, 0.3, log_sn, 0.1])
+        nll, g = ctx.nll_grad(gpx.MODEL_EXACT, cov, hyp)
+        nll_o, g_o = oracle.exact_nll(cov, X, y, hyp)
+        assert np.isfinite(nll_o)
+        assert abs(nll - nll_o) <= 1e-9 * max(1.0, abs(nll_o))
+        assert np.max(np.abs(g - g_o)) <= 1e-7 * max(1.0, np.max(np.abs(g_o)))
+    # non-finite hypers: the reference returns INF and an INF gradient (GP.cpp:132-134), never a status
+    bad = hyp0.copy()
+    bad[0] = np.nan
+    nll, g = ctx.nll_grad(gpx.MODEL_EXACT, 0, bad)
+    assert nll == np.inf and np.all(np.isinf(g))
+    ctx.close()
+
+
+# ---- full sizes --------------------------------------------------------------------------------------
+def _directional_check(ctx, gpx, model, hyp, h, jitter=0.0, tol=2e-6):
+    rng = np.random.default_rng(3)
+    v = rng.normal(size=hyp.size)
+    v /= np.linalg.norm(v)
+    nll, g = ctx.nll_grad(model, 0, hyp, jitter=jitter)
+    fp = ctx.nll_grad(model, 0, hyp + h * v, calc_grad=False, jitter=jitter)
+    fm = ctx.nll_grad(model, 0, hyp - h * v, calc_grad=False, jitter=jitter)
+    fd = (fp - fm) / (2 * h)
+    assert np.isfinite(nll) and np.all(np.isfinite(g))
+    assert abs(fd - g @ v) <= tol * max(1.0, np.linalg.norm(g)), (fd, g @ v)
+    return nll, g
+
+
+def test_exact_config1_n8192_properties(gpx):
+    """BASELINE.json configs[1]: n = 8192, d = 10 — gradient vs directional difference, invariance of
+    the NLL under a permutation of the training points, interpolation at the training inputs"""
+    n, d = 8192, 10
+    X, y, hyp, Xs = synth.make_problem(1, n, d, 256)
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    nll, g = _directional_check(ctx, gpx, gpx.MODEL_EXACT, hyp, 1e-4)
+    perm = np.random.default_rng(0).permutation(n)
+    ctx2 = gpx.Context()
+    ctx2.set_data(X[perm], y[perm])
+    nll_p, g_p = ctx2.nll_grad(gpx.MODEL_EXACT, 0, hyp)
+    assert abs(nll_p - nll) <= 1e-10 * abs(nll) and rel(g_p, g) <= 1e-8
+    # predictions: the posterior mean at training inputs reproduces y up to the noise shrinkage, the
+    # variance never leaves [sn2, sf2 + sn2]
+    ctx.prepare(gpx.MODEL_EXACT, 0, hyp)
+    far = np.full((2, d), 1e3)                              # no training point within reach: the prior comes back
+    mu, s2 = ctx.predict(np.vstack([X[:128], Xs, far]))
+    sf2, sn2 = np.exp(2 * hyp[d]), np.exp(2 * hyp[d + 1])
+    assert np.all(s2 >= sn2 * (1 - 1e-12)) and np.all(s2 <= (sf2 + sn2) * (1 + 1e-12))
+    assert np.all(mu[-2:] == hyp[d + 2]) and np.all(s2[-2:] == sf2 + sn2)
+    assert np.all(s2[:128] < 0.1 * (sf2 + sn2))            # 8192 points in d = 10 pin the function down
+    assert np.sqrt(np.mean((mu[:128] - y[:128]) ** 2)) < 3 * np.sqrt(sn2)
+    ctx.close()
+    ctx2.close()
+
+
+def test_exact_headline_n65536_directional_derivative(gpx):
+    """BASELINE.json configs[2], the benchmark size: 77 GB of factor + inverse on the device"""
+    n, d = 65536, 20
+    X, y, hyp, _ = synth.make_problem(2, n, d)
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    nll, g = _directional_check(ctx, gpx, gpx.MODEL_EXACT, hyp, 1e-4, tol=1e-5)
+    assert abs(nll - (-37305.7216831)) < 1e-3              # the value every bench run has printed
+    ctx.close()
+
+
+@pytest.mark.parametrize("model", ["fitc", "vfe"])
+def test_sparse_full_size_directional_derivative(gpx, model):
+    """configs[3] FITC n = 2^20, m = 1024, d = 20; VFE at n = 2^20, m = 2048, d = 50 (a quarter of
+    configs[4]'s rows: the synthetic targets alone take a minute of NumPy at 2^22)"""
+    n, m, d = (1 << 20, 1024, 20) if model == "fitc" else (1 << 20, 2048, 50)
+    seed = 20240601 + (3 if model == "fitc" else 4)
+    hyp = synth.eval_hyps(d)
+    X = synth.make_inputs(seed, n, d)
+    y = synth.make_targets(seed, X, hyp)
+    U = X[:m].copy()
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    ctx.set_inducing(U)
+    M = gpx.MODEL_FITC if model == "fitc" else gpx.MODEL_VFE
+    _directional_check(ctx, gpx, M, hyp, 1e-4, jitter=1e-8, tol=1e-5)
+    ctx.close()
