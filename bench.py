@@ -211,9 +211,12 @@ def main():
                         "config": sub["config"], "steps": args.sparse_steps})
 
     if D.rank == 0:
-        peak = C.c_double(0)
-        lib.check(lib.lib.gpx_bench_mfma_f64_peak(C.byref(peak)), "mfma_peak")
-        out["measured_bare_mfma_f64_tflops"] = peak.value
+        best = 0.0
+        for _ in range(3):   # the first pass runs while the clocks still ramp
+            peak = C.c_double(0)
+            lib.check(lib.lib.gpx_bench_mfma_f64_peak(C.byref(peak)), "mfma_peak")
+            best = max(best, peak.value)
+        out["measured_bare_mfma_f64_tflops"] = best   # register-operand MFMA loop, 16 accumulators, 2 waves/SIMD
         if not args.no_cpu_baseline and D.world == 1 and "exact" in want:
             out["cpu_baseline"] = cpu_baseline_exact(args.d, min(4096, args.n), args.n)  # ~20 s of CPU work
         print(json.dumps(out))

@@ -93,13 +93,10 @@ __device__ __forceinline__ double sfrag(const double* __restrict__ s, int row, i
     return KC ? s[row * (BK + 2) + k] : s[k * (BMN + 16) + row];
 }
 
-// NW = waves per workgroup: 4 (a 2 x 2 grid of waves) or 1 (the wave is the workgroup: no barrier
-// couples it to other waves; twice the operand traffic per flop)
-template <int TM, int TN, bool AKC, bool BKC, int NW = 4>
-__global__ __launch_bounds__(64 * NW, 2) void gemm_kernel(const GemmArgs g) {
-    constexpr int NT = 64 * NW;
-    constexpr int WG = NW == 4 ? 2 : 1;
-    constexpr int BM = 16 * WG * TM, BN = 16 * WG * TN;
+template <int TM, int TN, bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+    constexpr int NT = 256;
+    constexpr int BM = 32 * TM, BN = 32 * TN;
     constexpr int NLA = BM * 8 / NT, NLB = BN * 8 / NT;  // 16-B loads per thread and operand tile
     constexpr int LA = AKC ? BM * (BK + 2) : BK * (BM + 16);
     constexpr int LB = BKC ? BN * (BK + 2) : BK * (BN + 16);
@@ -155,7 +152,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_kernel(const GemmArgs g) {
     }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = NW == 4 ? (wave & 1) * (16 * TM) : 0, wn = NW == 4 ? (wave >> 1) * (16 * TN) : 0;
+    const int wm = (wave & 1) * (16 * TM), wn = (wave >> 1) * (16 * TN);
     const int l15 = lane & 15, l4 = lane >> 4;
 
     v4d acc[TN][TM];
@@ -332,13 +329,13 @@ __global__ void splitk_reduce_kernel(double* __restrict__ C, long ldc, const dou
     *c = beta == 0.0 ? s : s + beta * *c;
 }
 
-template <int TM, int TN, int NW = 4>
+template <int TM, int TN>
 void launch(hipStream_t st, int a_kc, int b_kc, const GemmArgs& g, int grid) {
-    const dim3 blk(64 * NW);
-    if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false, NW>), dim3(grid), blk, 0, st, g);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true, NW>), dim3(grid), blk, 0, st, g);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false, NW>), dim3(grid), blk, 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true, NW>), dim3(grid), blk, 0, st, g);
+    const dim3 blk(256);
+    if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), dim3(grid), blk, 0, st, g);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), dim3(grid), blk, 0, st, g);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), dim3(grid), blk, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), dim3(grid), blk, 0, st, g);
 }
 
 // ---- optional per-launch HIP-event timing of the large GEMMs (bench.py's roofline leg) -------
@@ -389,8 +386,6 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     }
     if (flags & GEMM_TILE64) bt = 64;
     if (flags & GEMM_TILE128) bt = 128;
-    const bool onewave = (flags & GEMM_TILE64W) != 0;
-    if (onewave) bt = 64;
     g.tiles_m = (int)((M + bt - 1) / bt);
     g.tiles_n = (int)((N + bt - 1) / bt);
     g.ntiles = (flags & GEMM_LOWER) ? g.tiles_m * (g.tiles_m + 1) / 2 : g.tiles_m * g.tiles_n;
@@ -414,8 +409,7 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
             g_prof.skipped++;
         }
     }
-    if (onewave) launch<4, 4, 1>(st, a_kc, b_kc, g, (int)grid);
-    else if (bt == 128) launch<4, 4>(st, a_kc, b_kc, g, (int)grid);
+    if (bt == 128) launch<4, 4>(st, a_kc, b_kc, g, (int)grid);
     else launch<2, 2>(st, a_kc, b_kc, g, (int)grid);
     if (g.splitk > 1) {
         const long tot = M * N;
@@ -433,16 +427,25 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
 }
 
 // bare MFMA loop: what the matrix pipe delivers with operands in registers
-__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
-    v4d acc[4];
-    for (int i = 0; i < 4; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
-    double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+__global__ __launch_bounds__(256, 2) void mfma_peak_kernel(double* out, int iters) {
+    // the GEMM's own register picture: 16 independent 16x16 accumulators, 4 + 4 operand values
+    v4d acc[4][4];
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) acc[j][i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double a[4], b[4];
+    for (int i = 0; i < 4; ++i) {
+        a[i] = 1.0 + (threadIdx.x + i) * 1e-3;
+        b[i] = 1.0 - (threadIdx.x + i) * 1e-3;
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j], a[i], acc[j][i], 0, 0, 0);
     }
     double s = 0;
-    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) s += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
     out[(long)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
@@ -481,9 +484,8 @@ int gpx_gemm_prof_end(double* total_ms, double* total_flops, long* launches, dou
 }
 
 int gpx_mfma_peak(double* tflops) {
-    // 2 waves per SIMD (what the GEMM runs with), 4 independent accumulators each; with 8 waves per
-    // SIMD the same loop only keeps the pipe 63 % busy (profiles/r01_pmc)
-    const int blocks = 256 * 2, iters = 32768;
+    // 2 waves per SIMD and 16 independent accumulators per wave, as in the GEMM
+    const int blocks = 256 * 2, iters = 8192;
     double* out = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&out), (size_t)blocks * 256 * 8));
     hipEvent_t e0, e1;
@@ -496,7 +498,7 @@ int gpx_mfma_peak(double* tflops) {
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    *tflops = (double)blocks * 4 * iters * 4 * 2048.0 / (ms * 1e-3) / 1e12;
+    *tflops = (double)blocks * 4 * iters * 16 * 2048.0 / (ms * 1e-3) / 1e12;
     (void)hipFree(out);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

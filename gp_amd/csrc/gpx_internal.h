@@ -50,7 +50,6 @@ static inline long gpx_ld(long n) {
 #define GEMM_TILE64 64      // force 64x64 tiles
 #define GEMM_TILE128 128    // force 128x128 tiles
 #define GEMM_NO_XCD 512      // keep the plain tile order for tall-skinny outputs (measurement only)
-#define GEMM_TILE64W 256    // 64x64 tiles, ONE wave per workgroup
 int gpx_gemm(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
              const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
              int flags);
