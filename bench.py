@@ -165,6 +165,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: anything a library prints there meanwhile (RCCL's
+    # version banner on the first collective) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     D = Dist()
     from gp_amd import lib, synth
     want = {"default": ("exact", "fitc"), "all": ("exact", "fitc", "vfe")}.get(args.workload, (args.workload,))
@@ -219,7 +225,8 @@ def main():
         out["measured_bare_mfma_f64_tflops"] = best   # register-operand MFMA loop, 16 accumulators, 2 waves/SIMD
         if not args.no_cpu_baseline and D.world == 1 and "exact" in want:
             out["cpu_baseline"] = cpu_baseline_exact(args.d, min(4096, args.n), args.n)  # ~20 s of CPU work
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if D.dist is not None:
         D.dist.destroy_process_group()
 
