@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int LA = AKC ? BM * (BK + 2) : BK * (BM + 16);
     constexpr int LB = BKC ? BN * (BK + 2) : BK * (BN + 16);
     __shared__ __attribute__((aligned(16))) double smem[LA + LB];
+    __shared__ __attribute__((aligned(16))) double smem1[(TM == 4 && TN == 4) ? LA + LB : 2];  // 2nd stage (direct-to-LDS loop)
     double* sA = smem;
     double* sB = smem + LA;
 
@@ -171,7 +172,76 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     // 32-bit byte offset per thread.  Vector instructions issued next to the MFMAs of the co-resident
     // wave delay them, so the address arithmetic of the generic path below costs matrix-pipe time.
     const bool interior = tfA && tfB && (klo + kt1 * BK <= g.K) && kt0 < kt1;
-    if (interior) {
+    if (TM == 4 && TN == 4 && interior && g.kscale == nullptr && !(g.flags & GEMM_NO_DLDS)) {
+        // Direct-to-LDS loop: global_load_lds_dwordx4 writes 64 lanes x 16 B = 1 KB straight into LDS
+        // (no staging registers, no ds_write, no address VALU beyond one add per load), two LDS stages,
+        // ONE barrier per K tile.  An M-contiguous wave-load is one k-row of the [16][BM+16] image; a
+        // K-contiguous one covers 8 rows of an unpadded [BM][16] image whose 16-B chunks are XOR-swizzled
+        // by (row >> 1) & 7 so that the fragment reads stay conflict-free.
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const long k00 = klo + kt0 * BK;
+        const char* pa = reinterpret_cast<const char*>(g.A) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
+        const char* pb = reinterpret_cast<const char*>(g.B) + (BKC ? k00 + (long)n0 * g.ldb : n0 + k00 * g.ldb) * 8;
+        const long ka = (AKC ? (long)BK : BK * g.lda) * 8, kb = (BKC ? (long)BK : BK * g.ldb) * 8;
+        // wave-load q = wv + 4 i (i = 0..3): M-contiguous -> k-row q; K-contiguous -> rows 8q .. 8q+7
+        const long ia = (AKC ? 32 * g.lda : 4 * g.lda) * 8, ib = (BKC ? 32 * g.ldb : 4 * g.ldb) * 8;
+        const int swz = (4 * wv + (lane >> 4)) & 7;  // ((row >> 1) & 7) of this lane's row, the same for every i
+        const unsigned ta = (unsigned)((AKC ? 2 * ((lane & 7) ^ swz) + (long)(8 * wv + (lane >> 3)) * g.lda
+                                            : 2 * lane + (long)wv * g.lda) * 8);
+        const unsigned tb = (unsigned)((BKC ? 2 * ((lane & 7) ^ swz) + (long)(8 * wv + (lane >> 3)) * g.ldb
+                                            : 2 * lane + (long)wv * g.ldb) * 8);
+        constexpr int QA = AKC ? 128 : BM + 16, QB = BKC ? 128 : BN + 16;  // doubles per wave-load in the LDS image
+        auto issue = [&](double* st) {
+            double* dA = st + wv * QA;
+            double* dB = st + LA + wv * QB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds(pa + i * ia + ta, (__attribute__((address_space(3))) void*)(dA + 4 * i * QA), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds(pb + i * ib + tb, (__attribute__((address_space(3))) void*)(dB + 4 * i * QB), 16, 0, 0);
+            pa += ka;
+            pb += kb;
+        };
+        auto fragA = [&](const double* st, int row, int k) {
+            return AKC ? st[row * 16 + ((((k >> 1) ^ (row >> 1)) & 7) << 1) + (k & 1)] : st[k * (BM + 16) + row];
+        };
+        auto fragB = [&](const double* st, int row, int k) {
+            return BKC ? st[LA + row * 16 + ((((k >> 1) ^ (row >> 1)) & 7) << 1) + (k & 1)] : st[LA + k * (BN + 16) + row];
+        };
+        auto multiply = [&](const double* st) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                double fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = fragA(st, wm + i * 16 + l15, kk * 4 + l4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = fragB(st, wn + j * 16 + l15, kk * 4 + l4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
+            }
+        };
+        issue(smem);
+        int kt = kt0;
+        for (; kt + 1 < kt1; kt += 2) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's part of tile kt is in LDS
+            __syncthreads();                     // ... and every other wave's; stage 1 is free again
+            issue(smem1);
+            multiply(smem);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+            if (kt + 2 < kt1) issue(smem);
+            multiply(smem1);
+        }
+        if (kt < kt1) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+            multiply(smem);
+        }
+    } else if (interior) {
         const long k00 = klo + kt0 * BK;
         const char* pa = reinterpret_cast<const char*>(g.A) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
         const char* pb = reinterpret_cast<const char*>(g.B) + (BKC ? k00 + (long)n0 * g.ldb : n0 + k00 * g.ldb) * 8;

@@ -46,9 +46,9 @@ int main(int argc, char** argv) {
     hipStreamCreate(&st);
     for (int v = 0; v < 4; ++v) {
         const int akc = v >> 1, bkc = v & 1;
-        printf("akc=%d bkc=%d  real ld: %6.1f TF   ld=0 (cached operands): %6.1f TF   64x64 tiles: %6.1f TF\n", akc, bkc,
+        printf("akc=%d bkc=%d  real ld: %6.1f TF   ld=0 (cached operands): %6.1f TF   register-staged loop: %6.1f TF\n", akc, bkc,
                run(st, n, ld, A, B, C, akc, bkc, 0), run(st, n, 0, A, B, C, akc, bkc, 0),
-               run(st, n, ld, A, B, C, akc, bkc, GEMM_TILE64));
+               run(st, n, ld, A, B, C, akc, bkc, GEMM_NO_DLDS));
         fflush(stdout);
     }
     return 0;
