@@ -24,6 +24,10 @@ import time
 
 import numpy as np
 
+# Streams share hardware queues round-robin (4 by default): with only 4, the collective's stream can land
+# on the queue of the GEMM the library keeps running beside it and wait for that GEMM to finish.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -62,16 +66,26 @@ class Dist:
             torch.cuda.set_device(self.local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
             self.torch, self.dist = torch, dist
+            self._views = {}
 
-    def allreduce_ptr(self, ptr, count):
-        """in-place sum all-reduce of `count` doubles at a raw device pointer (RCCL over xGMI)"""
+    def allreduce_on_stream(self, ptr, count, stream):
+        """ENQUEUE the in-place sum all-reduce of `count` doubles at a raw device pointer on the
+        library's own stream (RCCL over xGMI): torch sees that stream as an ExternalStream, the NCCL
+        process group orders its collective after it and makes it wait for the result — the host
+        does not block, so the m x m chains that follow are queued ahead of the GPU."""
         torch = self.torch
-
-        class _Mem:
-            __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-        t = torch.as_tensor(_Mem(), device=torch.device("cuda", self.local_rank))
-        self.dist.all_reduce(t)
-        torch.cuda.current_stream().synchronize()
+        key = (ptr, count, stream)
+        hit = self._views.get(key)
+        if hit is None:
+            class _Mem:
+                __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+            ext = torch.cuda.ExternalStream(stream, device=torch.device("cuda", self.local_rank))
+            with torch.cuda.stream(ext):
+                t = torch.as_tensor(_Mem(), device=torch.device("cuda", self.local_rank))
+            hit = self._views[key] = (ext, t)
+        ext, t = hit
+        with torch.cuda.stream(ext):
+            self.dist.all_reduce(t)
 
     def sync(self, lib):
         lib.check(lib.lib.gpx_device_synchronize(), "sync")
@@ -140,7 +154,7 @@ def run_sparse(D, lib, synth, model, n, m, d, steps, warmup, cfg_index):
     ctx.set_data(X, y)
     ctx.set_inducing(U)
     if D.dist is not None:
-        ctx.set_allreduce(D.allreduce_ptr)
+        ctx.set_allreduce_stream(D.allreduce_on_stream)
     M = lib.MODEL_FITC if model == "fitc" else lib.MODEL_VFE
     jitter = 1e-8   # (0.1 * noise_lb)^2 with the default noise_lb = 1e-3 (FITC.cpp:30, GP.cpp:28)
     dt, (nll, g), prof = timed(D, lib, lambda: ctx.nll_grad(M, lib.COV_SE_ARD, hyp, jitter=jitter), steps, warmup, 1e8)

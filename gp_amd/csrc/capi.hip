@@ -89,6 +89,15 @@ int gpx_set_inducing(gpx_ctx* c, const double* U, int64_t m) {
 int gpx_set_allreduce(gpx_ctx* c, gpx_allreduce_fn fn, void* user) {
     if (!c) return GPX_ERR_ARG;
     c->allreduce = fn;
+    c->allreduce_stream = nullptr;
+    c->allreduce_user = user;
+    return GPX_OK;
+}
+
+int gpx_set_allreduce_stream(gpx_ctx* c, gpx_allreduce_stream_fn fn, void* user) {
+    if (!c) return GPX_ERR_ARG;
+    c->allreduce_stream = fn;
+    c->allreduce = nullptr;
     c->allreduce_user = user;
     return GPX_OK;
 }

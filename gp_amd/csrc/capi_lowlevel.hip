@@ -1,5 +1,6 @@
 // capi_lowlevel.hip — device-memory helpers and the low-level dense entry points of the C ABI.
 #include "gpx_internal.h"
+#include "ctx.h"
 #include "../../include/gpx.h"
 
 extern "C" {
@@ -60,6 +61,11 @@ int gpx_dgemm_kscale(int b_kc, int64_t M, int64_t N, int64_t K, double alpha, co
     if (lda < K || ldb < (b_kc ? K : N) || ldc < M) return GPX_ERR_ARG;
     return gpx_gemm_splitk(0, 1, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, work, work_doubles,
                            kscale);
+}
+
+int gpx_dscal_stream(double* buf, int64_t count, double factor, void* hip_stream) {
+    if (!buf || count < 0) return GPX_ERR_ARG;
+    return gpx_vec_shift(static_cast<hipStream_t>(hip_stream), count, buf, 0.0, factor, buf);
 }
 
 /* measurement hooks */

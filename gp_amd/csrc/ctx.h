@@ -49,7 +49,8 @@ struct gpx_ctx {
     DevBuf Kxu, V, Bm, Cm, Kuu, Lu, Am, LA, Winv_u, Winv_A, Kuu_inv, A_inv, Wuu, Wd_u, Wd_A;
     DevBuf vn[8], vm[8], red;
     // all-reduce hook for row-sharded FITC/VFE
-    gpx_allreduce_fn allreduce = nullptr;
+    gpx_allreduce_fn allreduce = nullptr;                 // host-synchronous flavour
+    gpx_allreduce_stream_fn allreduce_stream = nullptr;   // stream-ordered flavour (preferred)
     void* allreduce_user = nullptr;
     // state left by gpx_prepare for gpx_predict
     int prepared_model = -1, prepared_cov = 0;

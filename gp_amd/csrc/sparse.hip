@@ -246,12 +246,18 @@ struct Sparse {
         hipLaunchKernelGGL(sum_partials_kernel, dim3(PW), dim3(256), 0, st, part(), (int)nblk(count), out, nout);
         return GPX_OK;
     }
-    // ready: event after which buf is complete (work queued behind it keeps running during the
-    // collective); without one the whole stream is drained first
-    int allreduce(double* buf, long count, hipEvent_t ready = nullptr) {
+    // The reduced values are consumed by work queued on `consumer`.  ready: event after which buf is
+    // complete (work queued on other streams behind it keeps running during the collective); without
+    // one, buf is produced on `consumer` itself.  Stream-ordered hook: the collective is enqueued on
+    // `consumer`, the host never waits.  Host-synchronous hook: wait for buf, call, return when reduced.
+    int allreduce(double* buf, long count, hipStream_t consumer, hipEvent_t ready = nullptr) {
+        if (c->allreduce_stream) {
+            if (ready) HIP_TRY(hipStreamWaitEvent(consumer, ready, 0));
+            return c->allreduce_stream(buf, count, consumer, c->allreduce_user) ? GPX_ERR_STATE : GPX_OK;
+        }
         if (!c->allreduce) return GPX_OK;
         if (ready) HIP_TRY(hipEventSynchronize(ready));
-        else HIP_TRY(hipStreamSynchronize(st));
+        else HIP_TRY(hipStreamSynchronize(consumer));
         return c->allreduce(buf, count, c->allreduce_user) ? GPX_ERR_STATE : GPX_OK;
     }
     // full symmetric inverse of a factored m x m matrix: Winv = L^-1, Inv = Winv^T Winv
@@ -365,7 +371,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         // all-reduce and the (narrow) factor chain of A run beside it
         if ((rc = gpx_gemm(st, 0, 1, n, m, m, 1.0, c->V.p, ldn, c->Winv_u.p, ldm, 0.0, c->Bm.p, ldn, GEMM_KLO_N))) return rc;
     }
-    if ((rc = s.allreduce(red, m * m + m + 16, c->ev[0]))) return rc;
+    if ((rc = s.allreduce(red, m * m + m + 16, c->st2, c->ev[0]))) return rc;
 
     // ---- phase 2 (side stream) ------------------------------------------------------------------
     // A = sn2*Kuu + S (FITC.cpp:217, VFE.cpp:174), factor, a = A^-1 F
@@ -449,7 +455,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Bm.p, ldn, c->Bm.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
                                   wv)))
             return rc;
-        if ((rc = s.allreduce(red, m * m + m + GPX_MAX_DIM + 32))) return rc;
+        if ((rc = s.allreduce(red, m * m + m + GPX_MAX_DIM + 32, st))) return rc;
         hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, red, m);
         // W_uu = sn2 A^-1 - Kuu^-1 + a a^T + B^T diag(w) B / sn2
         hipLaunchKernelGGL(mm_combine_full_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, h.sn2, c->A_inv.p, ldm, -1.0,
@@ -471,7 +477,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         s.finish_partials(m * m, c->scal.p + S_TRAS, 1);
         if ((rc = gpx_gemm(st, 0, 0, m, m, m, 1.0, c->Kuu_inv.p, ldm, red, m, 0.0, c->Am.p, ldm, 0))) return rc;
         if ((rc = gpx_gemm(st, 0, 0, m, m, m, 1.0, c->Am.p, ldm, c->Kuu_inv.p, ldm, 0.0, c->LA.p, ldm, 0))) return rc;
-        if ((rc = s.allreduce(redT, GPX_MAX_DIM + 32))) return rc;
+        if ((rc = s.allreduce(redT, GPX_MAX_DIM + 32, st))) return rc;
         // W_uu = 0.5 [a a^T + sn2 A^-1 - Kuu^-1 + G/sn2]
         hipLaunchKernelGGL(mm_combine_full_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, 0.5 * h.sn2, c->A_inv.p, ldm, -0.5,
                            c->Kuu_inv.p, ldm, 0.5, a_vec, 0.5 / h.sn2, c->LA.p, ldm, c->Wuu.p, ldm);
@@ -560,7 +566,7 @@ int gpx_sparse_prepare(gpx_ctx* c, int model, int cov, const double* hyp, double
                                       c->T.cap)))
                 return rc;
         }
-        if ((rc = s.allreduce(red, m * m + m))) return rc;
+        if ((rc = s.allreduce(red, m * m + m, st))) return rc;
         if (fitc) {
             // A = sn2*Kuu(no jitter) + S, and A + jitter*I inside the retry loop (FITC.cpp:180,195-196)
             const double dadd = -h.sn2 * kuu_add + (first ? 0.0 : *jitter);

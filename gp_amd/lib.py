@@ -130,6 +130,9 @@ lib.gpx_ctx_destroy.argtypes = [_vp]
 lib.gpx_set_data.argtypes = [_vp, _vp, _vp, _i64, _i64]
 lib.gpx_set_inducing.argtypes = [_vp, _vp, _i64]
 lib.gpx_set_allreduce.argtypes = [_vp, ALLREDUCE_FN, _vp]
+ALLREDUCE_STREAM_FN = C.CFUNCTYPE(_i, _vp, _i64, _vp, _vp)
+lib.gpx_set_allreduce_stream.argtypes = [_vp, ALLREDUCE_STREAM_FN, _vp]
+lib.gpx_dscal_stream.argtypes = [_vp, _i64, _d, _vp]
 lib.gpx_nll_grad.argtypes = [_vp, _i, _i, _vp, _i, _d, C.POINTER(_d), _vp]
 lib.gpx_prepare.argtypes = [_vp, _i, _i, _vp, C.POINTER(_d)]
 lib.gpx_predict.argtypes = [_vp, _vp, _i64, _vp, _vp]
@@ -179,6 +182,19 @@ class Context:
                 return 1
         self._cb = ALLREDUCE_FN(tramp)
         check(lib.gpx_set_allreduce(self._h, self._cb, None), "set_allreduce")
+
+    def set_allreduce_stream(self, fn):
+        """fn(device_ptr:int, count:int, hip_stream:int) -> None: ENQUEUE the in-place sum all-reduce of
+        `count` doubles on that stream and return without waiting."""
+        def tramp(buf, count, stream, user):
+            try:
+                fn(buf, count, stream or 0)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print("gpx allreduce callback failed:", e)
+                return 1
+        self._cb = ALLREDUCE_STREAM_FN(tramp)
+        check(lib.gpx_set_allreduce_stream(self._h, self._cb, None), "set_allreduce_stream")
 
     def nll_grad(self, model, cov, hyp, calc_grad=True, jitter=0.0):
         hyp = _c(hyp)

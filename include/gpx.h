@@ -69,6 +69,17 @@ int gpx_set_inducing(gpx_ctx* ctx, const double* U, int64_t m);
  * synchronised; must return 0 after the reduced values are visible to later device work. */
 typedef int (*gpx_allreduce_fn)(double* buf, int64_t count, void* user);
 int gpx_set_allreduce(gpx_ctx* ctx, gpx_allreduce_fn fn, void* user);
+/* Stream-ordered flavour of the same hook (no reference counterpart either): ENQUEUE the in-place
+ * sum-all-reduce on hip_stream (a hipStream_t of the library; buf is complete in that stream's
+ * order, the consumers are queued behind the call on it) and return without waiting — e.g.
+ * ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, (hipStream_t)hip_stream).  The host then
+ * never blocks inside an evaluation and the m x m chains stay queued ahead of the GPU.  Setting one
+ * flavour clears the other. */
+typedef int (*gpx_allreduce_stream_fn)(double* buf, int64_t count, void* hip_stream, void* user);
+int gpx_set_allreduce_stream(gpx_ctx* ctx, gpx_allreduce_stream_fn fn, void* user);
+/* buf *= factor, enqueued on hip_stream (no reference counterpart): lets a test stand in for "R ranks
+ * with identical shards" inside a stream-ordered hook, where the all-reduce is a multiplication by R. */
+int gpx_dscal_stream(double* buf, int64_t count, double factor, void* hip_stream);
 
 /* virtual GP::_calcNegLogProb(hyp, g, calc_grad) (GP.cpp:120-176), FITC::_calcNegLogProb
  * (FITC.cpp:201-319), VFE::_calcNegLogProb (VFE.cpp:165-249).  hyp and grad are HOST vectors of

@@ -133,6 +133,42 @@ def test_sparse_row_sharded_allreduce(gpx, model):
     ref.close()
 
 
+@pytest.mark.parametrize("model", ["fitc", "vfe"])
+def test_sparse_stream_ordered_allreduce_hook(gpx, model):
+    """The stream-ordered hook only ENQUEUES on the stream it is handed.  Two ranks with identical
+    shards make the sum-all-reduce a multiplication by 2, so ONE context with such a hook must
+    reproduce the evaluation of the doubled data set [X; X] without a hook — values and ordering."""
+    X, y, hyp, Xs, U = problem(0, 900, 5, 70)
+    jit = 1e-6
+    M = gpx.MODEL_FITC if model == "fitc" else gpx.MODEL_VFE
+    ref = gpx.Context()
+    ref.set_data(np.vstack([X, X]), np.concatenate([y, y]))
+    ref.set_inducing(U)
+    nll_ref, g_ref = ref.nll_grad(M, 0, hyp, jitter=jit)
+    ref.prepare(M, 0, hyp, jitter=jit)
+    mu_ref, s2_ref = ref.predict(Xs)
+    calls = []
+
+    def hook(ptr, count, stream):
+        calls.append((count, stream))
+        gpx.check(gpx.lib.gpx_dscal_stream(ptr, count, 2.0, stream), "dscal")
+
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    ctx.set_inducing(U)
+    ctx.set_allreduce_stream(hook)
+    for _ in range(2):                                    # twice: no state leaks between evaluations
+        nll, g = ctx.nll_grad(M, 0, hyp, jitter=jit)
+        assert abs(nll - nll_ref) <= 1e-9 * abs(nll_ref)
+        assert rel(g, g_ref) <= 1e-7
+    assert len(calls) == 4 and all(s for _, s in calls)   # two collectives per evaluation, on a real stream
+    ctx.prepare(M, 0, hyp, jitter=jit)
+    mu, s2 = ctx.predict(Xs)
+    assert rel(mu, mu_ref) <= 1e-9 and rel(s2, s2_ref) <= 1e-9
+    ref.close()
+    ctx.close()
+
+
 def test_sparse_golden_fixture_and_failure(gpx):
     g = np.load(GOLD)
     ctx = gpx.Context()
