@@ -124,14 +124,22 @@ __global__ __launch_bounds__(256) void cov_build_kernel(const double* __restrict
     }
 }
 
-template <int DC>
+// DC dimensions accumulate in registers; DL more (dims dim0+DC ..) accumulate in a per-thread LDS
+// column, so that up to 64 dimensions share ONE evaluation of the weights and of K (a second register
+// set of 32 accumulators spills)
+template <int DC, int DL = 0>
 __global__ __launch_bounds__(256) void pair_trace_kernel(const TraceArgs g) {
     __shared__ __attribute__((aligned(16))) double sa[DCH][64], sb[DCH][64];
-    __shared__ double red[4][DC + 2];
+    __shared__ double red[4][DC + DL + 2];
+    __shared__ double lacc[DL > 0 ? DL : 1][64];  // one column per lane quad (the quad is summed first)
     const int rg = threadIdx.x & 15, cg = threadIdx.x >> 4;
     double acc[DC];
 #pragma unroll
     for (int i = 0; i < DC; ++i) acc[i] = 0.0;
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int i = 0; i < DL; ++i) lacc[i][threadIdx.x] = 0.0;
+    }
     double sK = 0.0, tr = 0.0;
     const bool single = g.dpad <= DCH;  // the whole input fits one staging pass
 
@@ -232,6 +240,28 @@ __global__ __launch_bounds__(256) void pair_trace_kernel(const TraceArgs g) {
         };
         dims_chunk(std::integral_constant<int, 0>{});
         if constexpr (DC > DCH) dims_chunk(std::integral_constant<int, 1>{});
+        if constexpr (DL > 0) {
+            __syncthreads();
+            stage(sa, sb, g.Xt1, g.ld1, g.p, a0, g.Xt2, g.ld2, g.q, b0, g.dim0 + DC, DL, g.dpad);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < DL; ++i) {
+                const v2d a01 = *reinterpret_cast<const v2d*>(&sa[i][4 * rg]), a23 = *reinterpret_cast<const v2d*>(&sa[i][4 * rg + 2]);
+                const v2d b01 = *reinterpret_cast<const v2d*>(&sb[i][4 * cg]), b23 = *reinterpret_cast<const v2d*>(&sb[i][4 * cg + 2]);
+                const double xa[4] = {a01.x, a01.y, a23.x, a23.y}, xb[4] = {b01.x, b01.y, b23.x, b23.y};
+                double s = 0.0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double t = xa[r] - xb[c];
+                        s = fma(qk[c][r], t * t, s);
+                    }
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                if ((threadIdx.x & 3) == 0) lacc[i][threadIdx.x >> 2] += s;
+            }
+        }
     }
     // block reduction -> one partial row per workgroup
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -244,17 +274,23 @@ __global__ __launch_bounds__(256) void pair_trace_kernel(const TraceArgs g) {
         const double s = wave_sum(acc[i]);
         if (tx == 0) red[ty][i] = s;
     }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DL; ++i) {
+        const double s = wave_sum(ty == 0 ? lacc[i][tx] : 0.0);
+        if (tx == 0) red[ty][DC + i] = s;
+    }
     {
         const double s1 = wave_sum(sK), s2 = wave_sum(tr);
         if (tx == 0) {
-            red[ty][DC] = s1;
-            red[ty][DC + 1] = s2;
+            red[ty][DC + DL] = s1;
+            red[ty][DC + DL + 1] = s2;
         }
     }
     __syncthreads();
-    if (threadIdx.x < DC + 2) {
+    if (threadIdx.x < DC + DL + 2) {
         const int i = threadIdx.x;
-        g.partial[(long)blockIdx.x * (DC + 2) + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+        g.partial[(long)blockIdx.x * (DC + DL + 2) + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
     }
 }
 
@@ -316,22 +352,34 @@ int gpx_pair_trace(hipStream_t st, TraceArgs g, int d, double* partial_ws, long 
     g.partial = partial_ws;
     g.vec = ((reinterpret_cast<uintptr_t>(g.M1) & 15) == 0 && g.ldm1 % 2 == 0 &&
              (!g.M2 || ((reinterpret_cast<uintptr_t>(g.M2) & 15) == 0 && g.ldm2 % 2 == 0))) ? 1 : 0;
-    // 32 dimensions per pass (wider accumulator sets spill: the 4x4 patch already holds r2 and w K)
+    // up to 32 dimensions per pass in registers, plus up to 32 more in LDS accumulators when there are
+    // more: d <= 64 is ONE pass over the weights
     const int dc = g.dpad <= 8 ? 8 : g.dpad <= 16 ? 16 : g.dpad <= 24 ? 24 : 32;
-    const int width = dc + 2;
-    long nwg = ntiles < 2048 ? ntiles : 2048;
-    if (nwg * width > ws_doubles) nwg = ws_doubles / width;
-    if (nwg <= 0) return GPX_ERR_ARG;
-    for (int dim0 = 0; dim0 < g.dpad; dim0 += dc) {
+    for (int dim0 = 0; dim0 < g.dpad; dim0 += 64) {
+        const int rest = g.dpad - dim0;
+        const int dl = rest <= 32 ? 0 : rest <= 48 ? 16 : rest <= 56 ? 24 : 32;  // (a DL = 8 instance spills)
+        const int width = dc + dl + 2;
+        long nwg = ntiles < 2048 ? ntiles : 2048;
+        if (nwg * width > ws_doubles) nwg = ws_doubles / width;
+        if (nwg <= 0) return GPX_ERR_ARG;
         g.dim0 = dim0;
-        switch (dc) {
-            case 8: hipLaunchKernelGGL(pair_trace_kernel<8>, dim3((unsigned)nwg), dim3(256), 0, st, g); break;
-            case 16: hipLaunchKernelGGL(pair_trace_kernel<16>, dim3((unsigned)nwg), dim3(256), 0, st, g); break;
-            case 24: hipLaunchKernelGGL(pair_trace_kernel<24>, dim3((unsigned)nwg), dim3(256), 0, st, g); break;
-            default: hipLaunchKernelGGL(pair_trace_kernel<32>, dim3((unsigned)nwg), dim3(256), 0, st, g); break;
+        const dim3 gr((unsigned)nwg), bl(256);
+        if (dl == 0) {
+            switch (dc) {
+                case 8: hipLaunchKernelGGL((pair_trace_kernel<8, 0>), gr, bl, 0, st, g); break;
+                case 16: hipLaunchKernelGGL((pair_trace_kernel<16, 0>), gr, bl, 0, st, g); break;
+                case 24: hipLaunchKernelGGL((pair_trace_kernel<24, 0>), gr, bl, 0, st, g); break;
+                default: hipLaunchKernelGGL((pair_trace_kernel<32, 0>), gr, bl, 0, st, g); break;
+            }
+        } else {
+            switch (dl) {
+                case 16: hipLaunchKernelGGL((pair_trace_kernel<32, 16>), gr, bl, 0, st, g); break;
+                case 24: hipLaunchKernelGGL((pair_trace_kernel<32, 24>), gr, bl, 0, st, g); break;
+                default: hipLaunchKernelGGL((pair_trace_kernel<32, 32>), gr, bl, 0, st, g); break;
+            }
         }
         hipLaunchKernelGGL(trace_finish_kernel, dim3(width), dim3(256), 0, st, partial_ws, (int)nwg, width, dim0,
-                           dc, d, dim0 == 0 ? 1 : 0, out);
+                           dc + dl, d, dim0 == 0 ? 1 : 0, out);
     }
     HIP_TRY(hipGetLastError());
     return GPX_OK;
