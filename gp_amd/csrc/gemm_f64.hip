@@ -107,8 +107,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 
     int tile = blockIdx.x, ks = 0;
     if (g.splitk > 1) {
-        ks = tile % g.splitk;
-        tile /= g.splitk;
+        // slab-major: the workgroups that run together are the tiles of ONE K slab, walking it in step,
+        // so the operand rows they share come out of L2 (tile-major order re-read every operand tile
+        // from HBM once per output tile: 1.2 TB for the VFE Gram product instead of 69 GB)
+        ks = tile / g.ntiles;
+        tile -= ks * g.ntiles;
     }
     int bi, bj;
     if (g.xcd_rows) {
