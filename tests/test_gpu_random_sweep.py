@@ -1,0 +1,104 @@
+"""Seeded random sweep over shapes, kernels and hyper-parameters against the oracle: sizes straddle the
+64 / 128 tile and base-block edges (n, m = 63..65, 127..129, 191..193, 255..257, ...), d from 1 to 40."""
+import numpy as np
+import pytest
+
+import np_gp
+import oracle
+from gp_amd import synth
+
+pytestmark = pytest.mark.gpu
+EDGES = [63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 385, 511, 513]
+
+
+@pytest.fixture(scope="module")
+def gpx():
+    from gp_amd import lib
+    return lib
+
+
+def _hyp(rng, cov, d, y):
+    ls = rng.uniform(-0.5, 1.0, size=d) + 0.5 * np.log(d)
+    tail = [rng.uniform(-0.5, 0.5), rng.uniform(np.log(0.03), np.log(0.5)), rng.normal() * 0.2]
+    return np.concatenate([ls, tail]) if cov == 0 else np.concatenate([[ls.mean()], tail])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_exact_random(gpx, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice(EDGES)) + int(rng.integers(0, 2)) * 256
+    d = int(rng.integers(1, 41))
+    cov = int(rng.integers(0, 2))
+    t = int(rng.integers(1, 70))
+    X, y, _, Xs = synth.make_problem(10 + seed, n, d, t)
+    hyp = _hyp(rng, cov, d, y)
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    nll, g = ctx.nll_grad(gpx.MODEL_EXACT, cov, hyp)
+    nll_o, g_o = oracle.exact_nll(cov, X, y, hyp)
+    assert abs(nll - nll_o) <= 1e-9 * max(1.0, abs(nll_o)), (n, d, cov)
+    assert np.max(np.abs(g - g_o)) <= 1e-7 * max(1.0, np.max(np.abs(g_o))), (n, d, cov)
+    ctx.prepare(gpx.MODEL_EXACT, cov, hyp)
+    mu, s2, gmu, gs2 = ctx.predict_with_grad(Xs)
+    mu_o, s2_o, gmu_o, gs2_o = oracle.ExactState(cov, X, y, hyp).predict(Xs, grad=True)
+    sc = lambda a: max(1.0, np.max(np.abs(a)))
+    assert np.max(np.abs(mu - mu_o)) <= 1e-9 * sc(mu_o) and np.max(np.abs(s2 - s2_o)) <= 1e-9 * sc(s2_o)
+    assert np.max(np.abs(gmu - gmu_o)) <= 1e-8 * sc(gmu_o) and np.max(np.abs(gs2 - gs2_o)) <= 1e-8 * sc(gs2_o)
+    ctx.close()
+
+
+@pytest.mark.parametrize("model", ["fitc", "vfe"])
+@pytest.mark.parametrize("seed", range(12))
+def test_sparse_random(gpx, model, seed):
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.choice(EDGES)) + int(rng.integers(0, 3)) * 256
+    m = int(rng.choice(EDGES[:9]))
+    d = int(rng.integers(4, 30))          # d >= 4 keeps a few hundred inducing points independent
+    cov = int(rng.integers(0, 2))
+    X, y, _, Xs = synth.make_problem(40 + seed, n + m, d, 20)
+    U, X, y = X[n:], X[:n], y[:n]
+    hyp = _hyp(rng, cov, d, y)
+    jit = float(10.0 ** rng.uniform(-7, -4))
+    M = gpx.MODEL_FITC if model == "fitc" else gpx.MODEL_VFE
+    fo = oracle.fitc_nll if model == "fitc" else oracle.vfe_nll
+    fn = np_gp.fitc_nll if model == "fitc" else np_gp.vfe_nll
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    ctx.set_inducing(U)
+    nll, g = ctx.nll_grad(M, cov, hyp, jitter=jit)
+    nll_o, g_o = fo(cov, X, y, U, jit, hyp)
+    nll_n, g_n = fn(cov, X, y, U, jit, hyp)
+    # widened only by the measured disagreement of two CPU evaluations on the same inputs (conditioning)
+    tol_f = max(1e-9, 3 * abs(nll_n - nll_o) / max(1.0, abs(nll_o)))
+    tol_g = max(1e-7, 3 * np.max(np.abs(g_n - g_o)) / max(1.0, np.max(np.abs(g_o))))
+    assert abs(nll - nll_o) <= tol_f * max(1.0, abs(nll_o)), (n, m, d, cov, jit)
+    assert np.max(np.abs(g - g_o)) <= tol_g * max(1.0, np.max(np.abs(g_o))), (n, m, d, cov, jit)
+    ctx.prepare(M, cov, hyp, jitter=jit)
+    st = oracle.SparseState(model, cov, X, y, U, jit, hyp)
+    mu, s2 = ctx.predict(Xs)
+    mu_o, s2_o = st.predict(Xs)
+    tol_p = max(1e-9, 10 * tol_f)
+    assert np.max(np.abs(mu - mu_o)) <= tol_p * max(1.0, np.max(np.abs(mu_o)))
+    assert np.max(np.abs(s2 - s2_o)) <= tol_p * max(1.0, np.max(np.abs(s2_o)))
+    ctx.close()
+
+
+@pytest.mark.parametrize("n,d", [(3700, 5), (5000, 12)])
+def test_exact_mid_size_uses_the_128_tile_paths(gpx, n, d):
+    """n >= ~3600 is where the exact evaluation switches to 128 x 128 tiles (direct-to-LDS loop, K-range
+    ordering, batched epilogue).  The scalar oracle would need a minute here; the independent NumPy /
+    LAPACK closed form (tests/np_gp.py, itself pinned to the oracle in tests/test_oracle.py) checks
+    the same 1e-9 / 1e-7 bars, sqd_per_dim is O(n^2 d) memory so d stays small."""
+    X, y, hyp, Xs = synth.make_problem(3, n, d, 50)
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    nll, g = ctx.nll_grad(gpx.MODEL_EXACT, 0, hyp)
+    nll_n, g_n = np_gp.exact_nll(0, X, y, hyp)
+    assert abs(nll - nll_n) <= 1e-9 * abs(nll_n)
+    assert np.max(np.abs(g - g_n)) <= 1e-7 * max(1.0, np.max(np.abs(g_n)))
+    ctx.prepare(gpx.MODEL_EXACT, 0, hyp)
+    mu, s2 = ctx.predict(Xs)
+    mu_n, s2_n = np_gp.exact_predict(0, X, y, hyp, Xs)
+    assert np.max(np.abs(mu - mu_n)) <= 1e-9 * max(1.0, np.max(np.abs(mu_n)))
+    assert np.max(np.abs(s2 - s2_n)) <= 1e-9 * max(1.0, np.max(np.abs(s2_n)))
+    ctx.close()
