@@ -46,12 +46,37 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(long M, long K, double alph
     if (j >= K) return;
     const double* a = A + j * lda;
     double s0 = 0.0, s1 = 0.0;
-    long i = l + (tri ? j : 0);  // lower triangular: rows >= column
-    for (; i + 64 < M; i += 128) {
-        s0 = fma(a[i], x[i], s0);
-        s1 = fma(a[i + 64], x[i + 64], s1);
+    long i0 = tri ? j : 0;  // lower triangular: rows >= column
+    if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(x)) & 15) == 0) {
+        // long columns (the n x m products of the sparse models have only m of them): 16-B loads, eight
+        // of them in flight per lane, so that one wave per column still covers the HBM latency
+        if (i0 & 1) {
+            if (l == 0) s0 = a[i0] * x[i0];
+            ++i0;
+        }
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        const long nchunk = M > i0 ? (M - i0) / 512 : 0;  // 512 rows per wave and step
+        for (long c = 0; c < nchunk; ++c) {
+            const long i = i0 + 512 * c + 2 * l;
+            const v2d a0 = *reinterpret_cast<const v2d*>(a + i), a1 = *reinterpret_cast<const v2d*>(a + i + 128);
+            const v2d a2 = *reinterpret_cast<const v2d*>(a + i + 256), a3 = *reinterpret_cast<const v2d*>(a + i + 384);
+            const v2d x0 = *reinterpret_cast<const v2d*>(x + i), x1 = *reinterpret_cast<const v2d*>(x + i + 128);
+            const v2d x2 = *reinterpret_cast<const v2d*>(x + i + 256), x3 = *reinterpret_cast<const v2d*>(x + i + 384);
+            t0 = fma(a0.x, x0.x, fma(a0.y, x0.y, t0));
+            t1 = fma(a1.x, x1.x, fma(a1.y, x1.y, t1));
+            t2 = fma(a2.x, x2.x, fma(a2.y, x2.y, t2));
+            t3 = fma(a3.x, x3.x, fma(a3.y, x3.y, t3));
+        }
+        s0 += (t0 + t1) + (t2 + t3);
+        for (long r = i0 + 512 * nchunk + l; r < M; r += 64) s1 = fma(a[r], x[r], s1);
+    } else {
+        long i = l + i0;
+        for (; i + 64 < M; i += 128) {
+            s0 = fma(a[i], x[i], s0);
+            s1 = fma(a[i + 64], x[i + 64], s1);
+        }
+        for (; i < M; i += 64) s0 = fma(a[i], x[i], s0);
     }
-    for (; i < M; i += 64) s0 = fma(a[i], x[i], s0);
     double s = s0 + s1;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (l == 0) y[j] = beta == 0.0 ? alpha * s : beta * y[j] + alpha * s;
