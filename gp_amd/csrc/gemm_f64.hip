@@ -194,15 +194,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         const unsigned tb = (unsigned)((BKC ? 2 * ((lane & 7) ^ swz) + (long)(8 * wv + (lane >> 3)) * g.ldb
                                             : 2 * lane + (long)wv * g.ldb) * 8);
         constexpr int QA = AKC ? 128 : BM + 16, QB = BKC ? 128 : BN + 16;  // doubles per wave-load in the LDS image
+        // The loads are issued from inline assembly: the compiler's wait-count pass would otherwise
+        // wait for EVERY outstanding LDS-DMA load before each barrier, and the address form below (uniform
+        // 64-bit base in SGPRs + one loop-invariant 32-bit VGPR offset) needs no vector add per load.
+        // All vmcnt waits of this loop are therefore explicit.
+        auto lds_addr = [](const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; };
+        auto dlds16 = [](const char* base, unsigned voff, unsigned dst) {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst)
+                         : "memory", "m0");
+        };
         auto issue = [&](double* st) {
-            double* dA = st + wv * QA;
-            double* dB = st + LA + wv * QB;
+            const unsigned dA = lds_addr(st + wv * QA), dB = lds_addr(st + LA + wv * QB);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds(pa + i * ia + ta, (__attribute__((address_space(3))) void*)(dA + 4 * i * QA), 16, 0, 0);
+            for (int i = 0; i < 4; ++i) dlds16(pa + i * ia, ta, dA + 4 * i * QA * 8);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds(pb + i * ib + tb, (__attribute__((address_space(3))) void*)(dB + 4 * i * QB), 16, 0, 0);
+            for (int i = 0; i < 4; ++i) dlds16(pb + i * ib, tb, dB + 4 * i * QB * 8);
             pa += ka;
             pb += kb;
         };
@@ -227,16 +233,40 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                         acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
             }
         };
+        // L2 / TLB warm-up two tiles ahead: once operands stream from HBM over many pages (n >= 32768) a
+        // one-tile prefetch distance no longer covers the fetch (68.5 TFLOP/s against 73 with L2-resident
+        // operands).  Each thread touches ONE 128-B line of the tile after next with a 4-byte direct-to-LDS
+        // load into a dummy LDS word (no destination register to keep alive); the waits below leave that
+        // one load outstanding (vmcnt(1)), so only the tile that is needed next is waited for.
+        __shared__ int warm_sink[256];
+        const int th = tid & 127;
+        const bool wa = wv < 2;  // waves 0-1 warm A, waves 2-3 warm B (wave-uniform: the base stays in SGPRs)
+        const long wld = wa ? g.lda : g.ldb;
+        const bool wkc = wa ? AKC : BKC;
+        const unsigned woff = (unsigned)(wkc ? (long)th * wld * 8 : (long)(th >> 3) * wld * 8 + (th & 7) * 128);
+        const unsigned wdst = lds_addr(warm_sink + 64 * wv);
+        auto warm = [&]() {  // pa / pb point at the tile after the one just issued
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(woff), "s"(wa ? pa : pb), "s"(wdst)
+                         : "memory", "m0");
+        };
+        // waiting for tile j leaves the warm-up load issued after it outstanding, if there was one
         issue(smem);
+        if (kt0 + 1 < kt1) warm();
         int kt = kt0;
         for (; kt + 1 < kt1; kt += 2) {
-            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's part of tile kt is in LDS
+            __builtin_amdgcn_s_waitcnt(0x0f71);  // vmcnt(1): this wave's part of tile kt is in LDS
             __syncthreads();                     // ... and every other wave's; stage 1 is free again
             issue(smem1);
+            const bool more = kt + 2 < kt1;
+            if (more) warm();
             multiply(smem);
-            __builtin_amdgcn_s_waitcnt(0x0f70);
+            if (more) __builtin_amdgcn_s_waitcnt(0x0f71);
+            else __builtin_amdgcn_s_waitcnt(0x0f70);
             __syncthreads();
-            if (kt + 2 < kt1) issue(smem);
+            if (more) {
+                issue(smem);
+                if (kt + 3 < kt1) warm();
+            }
             multiply(smem1);
         }
         if (kt < kt1) {
