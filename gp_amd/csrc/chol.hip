@@ -386,8 +386,23 @@ int gpx_trtri(hipStream_t st, long n, const double* L, long ldl, const double* W
 }
 
 int gpx_lauum(hipStream_t st, long n, const double* W, long ldw, double* Out, long ldo) {
-    // Out_mn = sum_k W[k][m] W[k][n], k >= max(m, n) = m on the lower tiles
-    return gpx_gemm(st, 1, 1, n, n, n, 1.0, W, ldw, W, ldw, 0.0, Out, ldo, GEMM_LOWER | GEMM_KLO_M);
+    // Out = W^T W on the lower triangle, W lower triangular (stored W(k,m) at W[k + m*ldw], k >= m).
+    // One launch with k >= max(m, n) has trip counts that depend on BOTH tile indices, which the GEMM's
+    // square tile order cannot keep in step; above 16384 rows split instead:
+    //   Out11 = W11^T W11 + W21^T W21,  Out21 = W22^T W21,  Out22 = W22^T W22
+    // which puts 3/4 of the flops of each level into a full-K LOWER product and a product whose trip
+    // count depends on the M tile only.
+    if (n <= 16384) return gpx_gemm(st, 1, 1, n, n, n, 1.0, W, ldw, W, ldw, 0.0, Out, ldo, GEMM_LOWER | GEMM_KLO_M);
+    const long n1 = (n / 2 + 1023) / 1024 * 1024, n2 = n - n1;
+    const double* W21 = W + n1;
+    const double* W22 = W + n1 + n1 * ldw;
+    int rc = gpx_lauum(st, n1, W, ldw, Out, ldo);
+    if (rc) return rc;
+    rc = gpx_gemm(st, 1, 1, n1, n1, n2, 1.0, W21, ldw, W21, ldw, 1.0, Out, ldo, GEMM_LOWER);
+    if (rc) return rc;
+    rc = gpx_gemm(st, 1, 1, n2, n1, n2, 1.0, W22, ldw, W21, ldw, 0.0, Out + n1, ldo, GEMM_KLO_M);
+    if (rc) return rc;
+    return gpx_lauum(st, n2, W22, ldw, Out + n1 + n1 * ldo, ldo);
 }
 
 int gpx_trsm_left(hipStream_t st, long n, long nrhs, const double* L, long ldl, const double* Wd, double* B,

@@ -12,6 +12,8 @@
 // The MFMA's "A" operand is fed from matrix B and its "B" operand from matrix A, so that the
 // lane index (lane & 15) runs along M: accumulator stores and the beta*C read are 128-B
 // contiguous per 16 lanes in the column-major C.
+#include <array>
+#include <cstdlib>
 #include "gpx_internal.h"
 #include <cstdlib>
 
@@ -31,6 +33,7 @@ struct GemmArgs {
     int fastA, fastB;  // base pointer and ld allow 16-B vector loads
     const double* kscale;  // optional: op(A)(m,k) is multiplied by kscale[k] on its way to LDS (K-contiguous A only)
     int xcd_rows;      // tall-skinny outputs: the N tiles of one M tile run on ONE XCD (see kernel)
+    int sq_m, sq_n, nsuper;  // 8x8-tile squares, one per XCD at a time (nsuper == 0: plain tile order)
 };
 
 constexpr int BK = 16;
@@ -114,6 +117,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         tile -= ks * g.ntiles;
     }
     int bi, bj;
+    bool desc = false;  // walk the K range downwards (direct-to-LDS loop only; any order is correct)
     if (g.xcd_rows) {
         // Workgroup b runs on XCD b % 8.  For a tall-skinny output (few N tiles) give each XCD its own
         // M tiles and let that M tile's N tiles follow one another on it: the A rows are then fetched
@@ -122,6 +126,59 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         bi = ((tile >> 3) / g.tiles_n) * 8 + (tile & 7);
         bj = j;
         if (bi >= g.tiles_m) return;
+    } else if (g.nsuper) {
+        // Workgroup b runs on XCD b % 8 and an XCD holds 64 workgroups (128-tiles, 2 per CU) at a time: let
+        // those 64 be ONE 8x8 square of tiles that marches through K in step, so that each XCD's L2 fetches
+        // 8 + 8 operand tiles per K step for 64 consumers.  In plain tile order the sharers of an operand
+        // tile run 32 positions apart on their XCD, out of phase: at M = N = 32768 every A tile then came
+        // from HBM once per output tile (2.4 TB/s of L2 misses, 71 instead of 76 TFLOP/s).
+        //
+        // Triangular K ranges (one of KLO_* / KHI_*): the eight rows (or columns) of a square differ in
+        // trip count by 8 K tiles each, and a slot freed early is refilled early, so squares that all walk
+        // K the same way drift apart.  Squares therefore ALTERNATE on each XCD between
+        //   S: all 64 start together, walk K from the end of the range the tiles have in common (phases
+        //      equal), finish shortest row first, and
+        //   F: dispatched longest row first into the slots as they free up, walk K TOWARDS the common end:
+        //      a row that is 8 K tiles shorter starts 8 K tiles later, the phases are equal again and
+        //      all 64 finish together, so the next S square starts together.
+        const int w = (tile >> 3) & 63, sq = tile >> 9;
+        int sg = sq * 8 + (tile & 7);
+        if (sg >= g.nsuper) {
+            // the 36-tile squares on the diagonal of a LOWER product come last, packed densely
+            if (!(g.flags & GEMM_LOWER)) return;
+            const int t = tile - ((g.nsuper + 7) / 8) * 512;
+            if (t < 0) return;
+            const int d = t / 36, u = t % 36;
+            int r = 0;
+            while ((r + 1) * (r + 2) / 2 <= u) ++r;
+            bi = d * 8 + r;
+            bj = d * 8 + (u - r * (r + 1) / 2);
+            if (bi >= g.tiles_m) return;
+        } else {
+            if (g.flags & GEMM_HEAVY_LAST) sg = g.nsuper - 1 - sg;
+            const bool depM = g.flags & (GEMM_KLO_M | GEMM_KHI_M), depN = g.flags & (GEMM_KLO_N | GEMM_KHI_N);
+            int sm, sn;
+            if (g.flags & GEMM_LOWER) {  // squares strictly below the diagonal, row-major
+                sm = (int)((sqrt(8.0 * (double)sg + 1.0) - 1.0) * 0.5);
+                while (sm * (sm + 1) / 2 > sg) --sm;
+                while ((sm + 1) * (sm + 2) / 2 <= sg) ++sm;
+                sn = sg - sm * (sm + 1) / 2;
+                sm += 1;
+            } else if (depM) {  // the 8 XCDs work on squares of equal trip counts
+                sm = sg / g.sq_n;
+                sn = sg % g.sq_n;
+            } else {
+                sm = sg % g.sq_m;
+                sn = sg / g.sq_m;
+            }
+            // major index = the one the trip count depends on, longest first
+            const bool khi = g.flags & (GEMM_KHI_M | GEMM_KHI_N);
+            const int maj = khi ? 7 - (w >> 3) : (w >> 3), mnr = w & 7;
+            bi = sm * 8 + (depM ? maj : mnr);
+            bj = sn * 8 + (depM ? mnr : maj);
+            if (bi >= g.tiles_m || bj >= g.tiles_n) return;
+            if (depM || depN) desc = khi ? (sq & 1) : !(sq & 1);
+        }
     } else {
         if (g.flags & GEMM_HEAVY_LAST) tile = g.ntiles - 1 - tile;
         if (g.flags & GEMM_LOWER) {
@@ -182,10 +239,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         // K-contiguous one covers 8 rows of an unpadded [BM][16] image whose 16-B chunks are XOR-swizzled
         // by (row >> 1) & 7 so that the fragment reads stay conflict-free.
         const int wv = __builtin_amdgcn_readfirstlane(wave);
-        const long k00 = klo + kt0 * BK;
+        const bool down = __builtin_amdgcn_readfirstlane(desc);
+        const long k00 = klo + (down ? kt1 - 1 : kt0) * BK;
         const char* pa = reinterpret_cast<const char*>(g.A) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
         const char* pb = reinterpret_cast<const char*>(g.B) + (BKC ? k00 + (long)n0 * g.ldb : n0 + k00 * g.ldb) * 8;
-        const long ka = (AKC ? (long)BK : BK * g.lda) * 8, kb = (BKC ? (long)BK : BK * g.ldb) * 8;
+        const long ka = (AKC ? (long)BK : BK * g.lda) * (down ? -8 : 8), kb = (BKC ? (long)BK : BK * g.ldb) * (down ? -8 : 8);
         // wave-load q = wv + 4 i (i = 0..3): M-contiguous -> k-row q; K-contiguous -> rows 8q .. 8q+7
         const long ia = (AKC ? 32 * g.lda : 4 * g.lda) * 8, ib = (BKC ? 32 * g.ldb : 4 * g.ldb) * 8;
         const int swz = (4 * wv + (lane >> 4)) & 7;  // ((row >> 1) & 7) of this lane's row, the same for every i
@@ -447,6 +505,7 @@ struct GemmProf {
     double min_flops = 0;
     std::vector<hipEvent_t> ev;  // pairs
     std::vector<double> flops;
+    std::vector<std::array<long, 6>> shape;
     size_t used = 0;
     double skipped_flops = 0;
     long skipped = 0;
@@ -499,7 +558,28 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
         g.ldc = M;
     }
     g.xcd_rows = (!(flags & (GEMM_LOWER | GEMM_KLO_M | GEMM_KLO_N | GEMM_KHI_M | GEMM_KHI_N)) && g.splitk == 1 && g.tiles_n <= 32 && g.tiles_m >= 64 && !(flags & GEMM_NO_XCD)) ? 1 : 0;
-    const long grid = g.xcd_rows ? (long)((g.tiles_m + 7) / 8) * 8 * g.tiles_n : (long)g.ntiles * g.splitk;
+    // 8x8 squares of 128-tiles per XCD (see kernel): full products, LOWER with a full K range, and K ranges
+    // that depend on ONE of the tile indices
+    g.sq_m = (g.tiles_m + 7) / 8;
+    g.sq_n = (g.tiles_n + 7) / 8;
+    g.nsuper = 0;
+    long tail = 0;
+    {
+        const int tri = flags & (GEMM_KLO_M | GEMM_KLO_N | GEMM_KHI_M | GEMM_KHI_N);
+        const bool one_dep = tri == GEMM_KLO_M || tri == GEMM_KLO_N || tri == GEMM_KHI_M || tri == GEMM_KHI_N;
+        const bool form_ok = (flags & GEMM_LOWER) ? tri == 0 : (tri == 0 || one_dep);
+        if (!(flags & GEMM_NO_SQUARES) && form_ok && bt == 128 && !g.xcd_rows && g.splitk == 1 && g.tiles_m >= 16 && g.tiles_n >= 16) {
+            if (flags & GEMM_LOWER) {
+                g.nsuper = g.sq_m * (g.sq_m - 1) / 2;
+                tail = 36L * g.sq_m;
+            } else {
+                g.nsuper = g.sq_m * g.sq_n;
+            }
+        }
+    }
+    const long grid = g.xcd_rows ? (long)((g.tiles_m + 7) / 8) * 8 * g.tiles_n
+                      : g.nsuper ? (long)((g.nsuper + 7) / 8) * 512 + tail
+                                 : (long)g.ntiles * g.splitk;
     if (grid > 0x7fffffffL) return GPX_ERR_ARG;
     const double fl = useful_flops(M, N, K, flags);
     bool timed = false;
@@ -523,6 +603,7 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     if (timed) {
         (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
         g_prof.flops.push_back(fl);
+        g_prof.shape.push_back({M, N, K, (long)a_kc, (long)b_kc, (long)flags});
         g_prof.used += 2;
     }
     HIP_TRY(hipGetLastError());
@@ -564,6 +645,7 @@ int gpx_gemm_prof_begin(double min_flops, int max_launches) {
     g_prof.min_flops = min_flops;
     g_prof.used = 0;
     g_prof.flops.clear();
+    g_prof.shape.clear();
     g_prof.skipped_flops = 0;
     g_prof.skipped = 0;
     return GPX_OK;
@@ -578,6 +660,11 @@ int gpx_gemm_prof_end(double* total_ms, double* total_flops, long* launches, dou
         HIP_TRY(hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]));
         ms += t;
         fl += g_prof.flops[i / 2];
+        if (getenv("GPX_GEMM_LOG")) {  // per-launch shapes and rates of the timed evaluation(s), to stderr
+            const auto& q = g_prof.shape[i / 2];
+            fprintf(stderr, "gpx gemm M=%ld N=%ld K=%ld akc=%ld bkc=%ld flags=%ld  %.3f ms  %.1f TFLOP/s\n", q[0], q[1], q[2],
+                    q[3], q[4], q[5], t, g_prof.flops[i / 2] / (t * 1e-3) / 1e12);
+        }
     }
     *total_ms = ms;
     *total_flops = fl;

@@ -58,6 +58,37 @@ def test_gemm_lower_and_triangular_k_ranges():
         assert np.max(np.abs(np.tril(C) - np.tril(L.T @ L))) < 1e-11
 
 
+@pytest.mark.parametrize("n", [2048, 2304 + 130])
+def test_gemm_square_tile_order_all_forms(n):
+    """The 8x8-square tile order (one square per XCD, K walked up or down in alternate squares) must cover
+    every output tile exactly once for each operand form it applies to, ragged edges included."""
+    lib = _lib()
+    K = n
+    rng = np.random.default_rng(n)
+    D = rng.uniform(-1, 1, (n, K))
+    E = rng.uniform(-1, 1, (n, K))
+    L = np.tril(rng.uniform(-1, 1, (n, n)))
+    sq = lib.GEMM_TILE128  # >= 16 x 16 tiles of 128: the square order is the default
+    tol = 1e-13 * K
+    C0 = rng.uniform(-1, 1, (n, n))
+    C = lib.dgemm(D, E, C0, alpha=0.5, beta=-2.0, flags=sq)
+    assert np.max(np.abs(C - (0.5 * D @ E.T - 2.0 * C0))) <= tol
+    C = lib.dgemm(D, D, flags=lib.GEMM_LOWER | sq)
+    assert np.max(np.abs(np.tril(C) - np.tril(D @ D.T))) <= tol
+    # A lower triangular, k <= m (trip count grows with the M tile), heavy tiles first
+    C = lib.dgemm(L, E.T.copy(), flags=lib.GEMM_KHI_M | lib.GEMM_HEAVY_LAST | sq, b_kc=True)
+    assert np.max(np.abs(C - L @ E)) <= tol
+    # B(n,k) = L[n,k], k <= n (trip count grows with the N tile)
+    C = lib.dgemm(D, L, flags=lib.GEMM_KHI_N | sq)
+    assert np.max(np.abs(C - D @ L.T)) <= tol
+    # B(n,k) = W[k][n], W lower: k >= n
+    C = lib.dgemm(D, L.T.copy(), flags=lib.GEMM_KLO_N | sq, b_kc=True)
+    assert np.max(np.abs(C - D @ L)) <= tol
+    # A(m,k) = W[k][m], W lower: k >= m
+    C = lib.dgemm(L.T.copy(), E, flags=lib.GEMM_KLO_M | sq, a_kc=True)
+    assert np.max(np.abs(C - L.T @ E.T)) <= tol
+
+
 def test_gemm_splitk_tall():
     lib = _lib()
     M, N, K = 96, 160, 40000

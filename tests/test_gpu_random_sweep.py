@@ -83,12 +83,13 @@ def test_sparse_random(gpx, model, seed):
     ctx.close()
 
 
-@pytest.mark.parametrize("n,d", [(3700, 5), (5000, 12)])
+@pytest.mark.parametrize("n,d", [(3700, 5), (5000, 12), (17500, 3)])
 def test_exact_mid_size_uses_the_128_tile_paths(gpx, n, d):
     """n >= ~3600 is where the exact evaluation switches to 128 x 128 tiles (direct-to-LDS loop, K-range
     ordering, batched epilogue).  The scalar oracle would need a minute here; the independent NumPy /
     LAPACK closed form (tests/np_gp.py, itself pinned to the oracle in tests/test_oracle.py) checks
-    the same 1e-9 / 1e-7 bars, sqd_per_dim is O(n^2 d) memory so d stays small."""
+    the same 1e-9 / 1e-7 bars, sqd_per_dim is O(n^2 d) memory so d stays small.  n = 17500 > 16384 adds
+    the split of the W^T W product (9216 + 8284 rows) and the square tile order of the large products."""
     X, y, hyp, Xs = synth.make_problem(3, n, d, 50)
     ctx = gpx.Context()
     ctx.set_data(X, y)
