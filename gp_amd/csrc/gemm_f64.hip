@@ -568,13 +568,16 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
         const int tri = flags & (GEMM_KLO_M | GEMM_KLO_N | GEMM_KHI_M | GEMM_KHI_N);
         const bool one_dep = tri == GEMM_KLO_M || tri == GEMM_KLO_N || tri == GEMM_KHI_M || tri == GEMM_KHI_N;
         const bool form_ok = (flags & GEMM_LOWER) ? tri == 0 : (tri == 0 || one_dep);
-        if (!(flags & GEMM_NO_SQUARES) && form_ok && bt == 128 && !g.xcd_rows && g.splitk == 1 && g.tiles_m >= 16 && g.tiles_n >= 16) {
+        if (!(flags & GEMM_NO_SQUARES) && form_ok && bt == 128 && !g.xcd_rows && g.splitk == 1 && ((g.tiles_m >= 16 && g.tiles_n >= 16) || (flags & GEMM_FORCE_SQUARES))) {
             if (flags & GEMM_LOWER) {
                 g.nsuper = g.sq_m * (g.sq_m - 1) / 2;
                 tail = 36L * g.sq_m;
             } else {
                 g.nsuper = g.sq_m * g.sq_n;
             }
+            // fewer than 8 squares per XCD leave the XCDs unevenly loaded (8192 LOWER: 28 squares, 9.5 ms
+            // against 8.7 ms in plain order)
+            if (g.nsuper < 64 && !(flags & GEMM_FORCE_SQUARES)) g.nsuper = 0, tail = 0;
         }
     }
     const long grid = g.xcd_rows ? (long)((g.tiles_m + 7) / 8) * 8 * g.tiles_n
@@ -716,6 +719,17 @@ int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, 
         if (!(flags & (GEMM_TILE64 | GEMM_TILE128)) && t128 * s128 >= 1024) {
             flags |= GEMM_TILE128;
             splitk = s128;
+            // 512 workgroups run at a time (2 per CU): among the slab counts down to s128/2 take the one
+            // whose tiles x slabs fill whole rounds best (m = 1024 LOWER: 36 tiles x 64 = 4.5 rounds,
+            // x 56 = 3.94; m = 2048: 136 x 16 = 4.25, x 15 = 3.98)
+            const long tm = (M + 127) / 128, tn = (N + 127) / 128;
+            const long ta = (flags & GEMM_LOWER) ? tm * (tm + 1) / 2 : tm * tn;
+            double best = 0;
+            for (int sk = s128; sk > s128 / 2 && sk >= 1; --sk) {
+                const long w = ta * sk;
+                const double eff = (double)w / (double)((w + 511) / 512 * 512);
+                if (eff > best + 1e-9) best = eff, splitk = sk;
+            }
         } else {
             const long tiles = ((M + 63) / 64) * ((N + 63) / 64) / ((flags & GEMM_LOWER) ? 2 : 1);
             while (splitk < 64 && tiles * splitk < 1024 && kt / (splitk * 2) >= 16 &&

@@ -52,6 +52,7 @@ static inline long gpx_ld(long n) {
 #define GEMM_NO_DLDS 256     // register-staged interior loop instead of direct-to-LDS loads (measurement only)
 #define GEMM_NO_XCD 512      // keep the plain tile order for tall-skinny outputs (measurement only)
 #define GEMM_NO_SQUARES 1024 // plain tile order instead of one 8x8 square of 128-tiles per XCD (measurement only)
+#define GEMM_FORCE_SQUARES 2048  // the square order even where it does not pay (few squares; tests)
 int gpx_gemm(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
              const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
              int flags);

@@ -68,7 +68,7 @@ def test_gemm_square_tile_order_all_forms(n):
     D = rng.uniform(-1, 1, (n, K))
     E = rng.uniform(-1, 1, (n, K))
     L = np.tril(rng.uniform(-1, 1, (n, n)))
-    sq = lib.GEMM_TILE128  # >= 16 x 16 tiles of 128: the square order is the default
+    sq = lib.GEMM_TILE128 | lib.GEMM_FORCE_SQUARES  # the default from 64 squares on (n >= 8192); forced here
     tol = 1e-13 * K
     C0 = rng.uniform(-1, 1, (n, n))
     C = lib.dgemm(D, E, C0, alpha=0.5, beta=-2.0, flags=sq)
@@ -101,6 +101,18 @@ def test_gemm_splitk_tall():
     D = rng.uniform(-1, 1, (M, K))
     C = lib.dgemm(D, D, a_kc=True, b_kc=True, flags=lib.GEMM_LOWER, splitk_work=64 * M * M)
     assert np.max(np.abs(np.tril(C) - np.tril(D @ D.T))) < 1e-10
+
+
+def test_gemm_splitk_gram_slab_count_that_fills_whole_rounds():
+    """m = 1024 LOWER over a long K: 36 tiles of 128, the slab count drops from 64 to 56 (3.94 rounds of
+    512 workgroups instead of 4.5), so the K range is cut into unequal, non-power-of-two slabs."""
+    lib = _lib()
+    M, K = 1024, 1 << 18
+    rng = np.random.default_rng(11)
+    D = rng.uniform(-1, 1, (M, K))
+    C0 = np.tril(rng.uniform(-1, 1, (M, M)))
+    C = lib.dgemm(D, D, C0, a_kc=True, b_kc=True, beta=1.0, flags=lib.GEMM_LOWER, splitk_work=64 * M * M)
+    assert np.max(np.abs(np.tril(C) - np.tril(D @ D.T + C0))) < 1e-13 * K
 
 
 @pytest.mark.parametrize("shape", [(96, 160, 40000), (1024, 1024, 8192), (130, 70, 1000)])

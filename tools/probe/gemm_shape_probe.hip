@@ -26,8 +26,9 @@ int main(int argc, char** argv) {
     long maxel = 0, maxc = 0;
     for (auto& c : cases) {
         if (c.size() < 4) return 2;
-        const long big = c[0] > c[1] ? c[0] : c[1];
-        const long el = c[3] * (big > c[2] ? big : c[2]);
+        const bool akc = c.size() > 4 && c[4], bkc = c.size() > 5 && c[5];
+        const long ea = c[3] * (akc ? c[0] : c[2]), eb = c[3] * (bkc ? c[1] : c[2]);
+        const long el = ea > eb ? ea : eb;
         if (el > maxel) maxel = el;
         if (c[0] * c[1] > maxc) maxc = c[0] * c[1];
     }
