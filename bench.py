@@ -133,13 +133,28 @@ def timed(D, lib, fn, steps, warmup, prof_min_flops):
     return D.max_over_ranks(dt), out, prof
 
 
-def run_exact(D, lib, synth, n, d, steps, warmup):
-    X, y, hyp, _ = synth.make_problem(2, n, d)
+def run_exact(D, lib, synth, n, d, steps, warmup, predict_t):
+    X, y, hyp, Xs = synth.make_problem(2, n, d, max(predict_t, 1))
     ctx = lib.Context(D.local_rank)
     ctx.set_data(X, y)
     dt, (nll, g), prof = timed(D, lib, lambda: ctx.nll_grad(lib.MODEL_EXACT, lib.COV_SE_ARD, hyp), steps, warmup, 1e9)
+    pred = None
+    if predict_t > 0:
+        # SURVEY 8(d) secondary metric: test points per second of _predict (mean + variance) after _setK;
+        # host Xs in, host mu / s2 out (t*(d+2)*8 bytes over PCIe, included)
+        t0 = time.perf_counter()
+        ctx.prepare(lib.MODEL_EXACT, lib.COV_SE_ARD, hyp)
+        t_prep = time.perf_counter() - t0
+        ctx.predict(Xs[:256])
+        t0 = time.perf_counter()
+        mu, s2 = ctx.predict(Xs)
+        t_pred = time.perf_counter() - t0
+        fl = 2.0 * predict_t * n * d + float(predict_t) * n * n   # K* build + ONE triangular solve
+        pred = {"value": predict_t / t_pred, "unit": "test points/s", "t": predict_t, "ms": 1e3 * t_pred,
+                "algorithmic_tflops": fl / t_pred / 1e12, "prepare_ms (_setK: build + factor + alpha)": 1e3 * t_prep,
+                "mean_abs_mu": float(abs(mu).mean()), "mean_s2": float(s2.mean())}
     ctx.close()
-    return dt, nll, prof
+    return dt, nll, prof, pred
 
 
 def run_sparse(D, lib, synth, model, n, m, d, steps, warmup, cfg_index):
@@ -177,6 +192,7 @@ def main():
     ap.add_argument("--vfe-d", type=int, default=50)
     ap.add_argument("--sparse-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--predict-t", type=int, default=4096, help="test points of the exact-GP predict timing (0: skip)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON: anything a library prints there meanwhile (RCCL's
@@ -193,7 +209,7 @@ def main():
 
     if "exact" in want:
         n, d = args.n, args.d
-        dt, nll, prof = run_exact(D, lib, synth, n, d, args.steps, args.warmup)
+        dt, nll, prof, pred = run_exact(D, lib, synth, n, d, args.steps, args.warmup, args.predict_t)
         evals = args.steps * D.world
         gemm_tf = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] > 0 else 0.0
         alg_tf = float(n) ** 3 * args.steps / dt / 1e12   # per GPU
@@ -211,6 +227,8 @@ def main():
                          "algorithmic_flops_per_eval": prof["gemm_flops"],
                          "flops_in_untimed_small_launches_per_eval": prof["small_flops"]},
         })
+        if pred is not None:
+            out["predict"] = pred
     for model in ("fitc", "vfe"):
         if model not in want:
             continue
