@@ -568,7 +568,7 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
         const int tri = flags & (GEMM_KLO_M | GEMM_KLO_N | GEMM_KHI_M | GEMM_KHI_N);
         const bool one_dep = tri == GEMM_KLO_M || tri == GEMM_KLO_N || tri == GEMM_KHI_M || tri == GEMM_KHI_N;
         const bool form_ok = (flags & GEMM_LOWER) ? tri == 0 : (tri == 0 || one_dep);
-        if (!(flags & GEMM_NO_SQUARES) && form_ok && bt == 128 && !g.xcd_rows && g.splitk == 1 && ((g.tiles_m >= 16 && g.tiles_n >= 16) || (flags & GEMM_FORCE_SQUARES))) {
+        if (!(flags & GEMM_NO_SQUARES) && form_ok && bt == 128 && !g.xcd_rows && g.splitk == 1 && ((g.tiles_m >= 16 && (g.tiles_n >= 16 || g.tiles_n == 8)) || (flags & GEMM_FORCE_SQUARES))) {
             if (flags & GEMM_LOWER) {
                 g.nsuper = g.sq_m * (g.sq_m - 1) / 2;
                 tail = 36L * g.sq_m;
