@@ -113,8 +113,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         // slab-major: the workgroups that run together are the tiles of ONE K slab, walking it in step,
         // so the operand rows they share come out of L2 (tile-major order re-read every operand tile
         // from HBM once per output tile: 1.2 TB for the VFE Gram product instead of 69 GB)
-        ks = tile / g.ntiles;
-        tile -= ks * g.ntiles;
+        if (g.splitk % 8 == 0) {
+            // workgroup b runs on XCD b % 8: give every XCD its own slabs, so that the operand rows of a
+            // slab enter ONE L2 (the m = 1024 Gram product fetched 65 GB for 8.6 GB of operands when the
+            // tiles of each slab were dealt round the eight XCDs)
+            const int l = tile >> 3;
+            ks = (l / g.ntiles) * 8 + (tile & 7);
+            tile = l % g.ntiles;
+        } else {
+            ks = tile / g.ntiles;
+            tile -= ks * g.ntiles;
+        }
     }
     int bi, bj;
     bool desc = false;  // walk the K range downwards (direct-to-LDS loop only; any order is correct)
@@ -719,16 +728,21 @@ int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, 
         if (!(flags & (GEMM_TILE64 | GEMM_TILE128)) && t128 * s128 >= 1024) {
             flags |= GEMM_TILE128;
             splitk = s128;
-            // 512 workgroups run at a time (2 per CU): among the slab counts down to s128/2 take the one
-            // whose tiles x slabs fill whole rounds best (m = 1024 LOWER: 36 tiles x 64 = 4.5 rounds,
-            // x 56 = 3.94; m = 2048: 136 x 16 = 4.25, x 15 = 3.98)
+            // 512 workgroups run at a time (2 per CU): take the slab count whose tiles x slabs fill whole
+            // rounds best (m = 1024 LOWER: 36 tiles x 64 = 4.5 rounds, x 56 = 3.94).  A multiple of 8 lets
+            // every slab live on ONE XCD (see kernel), which is worth more than the last percent of a
+            // round: m = 2048: 136 x 15 = 3.98 rounds, but 136 x 64 = 17.0 with XCD-private slabs.
             const long tm = (M + 127) / 128, tn = (N + 127) / 128;
             const long ta = (flags & GEMM_LOWER) ? tm * (tm + 1) / 2 : tm * tn;
+            int smax = s128;
+            while (smax + 8 <= 64 && kt / (smax + 8) >= 32 && (long)(smax + 8) * M * N <= work_doubles) smax += 8;
             double best = 0;
-            for (int sk = s128; sk > s128 / 2 && sk >= 1; --sk) {
+            for (int sk = smax; sk > s128 / 2 && sk >= 1; --sk) {
+                if (sk > s128 && sk % 8) continue;
                 const long w = ta * sk;
-                const double eff = (double)w / (double)((w + 511) / 512 * 512);
-                if (eff > best + 1e-9) best = eff, splitk = sk;
+                double score = (double)w / (double)((w + 511) / 512 * 512) - 0.0005 * sk;
+                if (sk % 8 == 0) score += 0.05;
+                if (score > best + 1e-9) best = score, splitk = sk;
             }
         } else {
             const long tiles = ((M + 63) / 64) * ((N + 63) / 64) / ((flags & GEMM_LOWER) ? 2 : 1);
