@@ -14,6 +14,7 @@
 // contiguous per 16 lanes in the column-major C.
 #include <array>
 #include <cstdlib>
+#include <type_traits>
 #include "gpx_internal.h"
 #include <cstdlib>
 
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     // 32-bit byte offset per thread.  Vector instructions issued next to the MFMAs of the co-resident
     // wave delay them, so the address arithmetic of the generic path below costs matrix-pipe time.
     const bool interior = tfA && tfB && (klo + kt1 * BK <= g.K) && kt0 < kt1;
-    if (TM == 4 && TN == 4 && interior && g.kscale == nullptr && !(g.flags & GEMM_NO_DLDS)) {
+    if (TM == 4 && TN == 4 && interior && !(g.flags & GEMM_NO_DLDS)) {
         // Direct-to-LDS loop: global_load_lds_dwordx4 writes 64 lanes x 16 B = 1 KB straight into LDS
         // (no staging registers, no ds_write, no address VALU beyond one add per load), two LDS stages,
         // ONE barrier per K tile.  An M-contiguous wave-load is one k-row of the [16][BM+16] image; a
@@ -270,35 +271,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst)
                          : "memory", "m0");
         };
-        auto issue = [&](double* st) {
-            const unsigned dA = lds_addr(st + wv * QA), dB = lds_addr(st + LA + wv * QB);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dlds16(pa + i * ia, ta, dA + 4 * i * QA * 8);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dlds16(pb + i * ib, tb, dB + 4 * i * QB * 8);
-            pa += ka;
-            pb += kb;
-        };
         auto fragA = [&](const double* st, int row, int k) {
             return AKC ? st[row * 16 + ((((k >> 1) ^ (row >> 1)) & 7) << 1) + (k & 1)] : st[k * (BM + 16) + row];
         };
         auto fragB = [&](const double* st, int row, int k) {
             return BKC ? st[LA + row * 16 + ((((k >> 1) ^ (row >> 1)) & 7) << 1) + (k & 1)] : st[LA + k * (BN + 16) + row];
-        };
-        auto multiply = [&](const double* st) {
-#pragma unroll
-            for (int kk = 0; kk < BK / 4; ++kk) {
-                double fa[TM], fb[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = fragA(st, wm + i * 16 + l15, kk * 4 + l4);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = fragB(st, wn + j * 16 + l15, kk * 4 + l4);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
-            }
         };
         // L2 / TLB warm-up two tiles ahead: once operands stream from HBM over many pages (n >= 32768) a
         // one-tile prefetch distance no longer covers the fetch (68.5 TFLOP/s against 73 with L2-resident
@@ -316,31 +293,81 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(woff), "s"(wa ? pa : pb), "s"(wdst)
                          : "memory", "m0");
         };
-        // waiting for tile j leaves the warm-up load issued after it outstanding, if there was one
-        issue(smem);
-        if (kt0 + 1 < kt1) warm();
-        int kt = kt0;
-        for (; kt + 1 < kt1; kt += 2) {
-            __builtin_amdgcn_s_waitcnt(0x0f71);  // vmcnt(1): this wave's part of tile kt is in LDS
-            __syncthreads();                     // ... and every other wave's; stage 1 is free again
-            issue(smem1);
-            const bool more = kt + 2 < kt1;
-            if (more) warm();
-            multiply(smem);
-            if (more) __builtin_amdgcn_s_waitcnt(0x0f71);
-            else __builtin_amdgcn_s_waitcnt(0x0f70);
-            __syncthreads();
-            if (more) {
-                issue(smem);
-                if (kt + 3 < kt1) warm();
+        // K-dimension scale (A^T diag(s) B, K-contiguous A): the 16 scale values of a K tile travel to LDS
+        // beside the operand tiles (wave 0: one 4-byte load per lane, the upper 32 lanes write a second
+        // copy) and multiply the A fragments on their way to the MFMAs.
+        __shared__ __attribute__((aligned(16))) double sks[2][32];
+        const char* ps = reinterpret_cast<const char*>(g.kscale) + k00 * 8;
+        const long ksd = down ? -(long)BK * 8 : (long)BK * 8;
+        const unsigned soff = (unsigned)((lane & 31) * 4);
+        auto run = [&](auto SC) {
+            constexpr bool scaled = decltype(SC)::value;
+            auto issue = [&](int stage) {
+                double* st = stage ? smem1 : smem;
+                const unsigned dA = lds_addr(st + wv * QA), dB = lds_addr(st + LA + wv * QB);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dlds16(pa + i * ia, ta, dA + 4 * i * QA * 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dlds16(pb + i * ib, tb, dB + 4 * i * QB * 8);
+                if (scaled) {
+                    if (wv == 0)
+                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(soff), "s"(ps),
+                                     "s"(lds_addr(sks[stage]))
+                                     : "memory", "m0");
+                    ps += ksd;
+                }
+                pa += ka;
+                pb += kb;
+            };
+            auto multiply = [&](int stage) {
+                const double* st = stage ? smem1 : smem;
+#pragma unroll
+                for (int kk = 0; kk < BK / 4; ++kk) {
+                    double fa[TM], fb[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[i] = fragA(st, wm + i * 16 + l15, kk * 4 + l4);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[j] = fragB(st, wn + j * 16 + l15, kk * 4 + l4);
+                    if (scaled) {
+                        const double sc = sks[stage][kk * 4 + l4];
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) fa[i] *= sc;
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
+                }
+            };
+            // waiting for tile j leaves the warm-up load issued after it outstanding, if there was one
+            issue(0);
+            if (kt0 + 1 < kt1) warm();
+            int kt = kt0;
+            for (; kt + 1 < kt1; kt += 2) {
+                __builtin_amdgcn_s_waitcnt(0x0f71);  // vmcnt(1): this wave's part of tile kt is in LDS
+                __syncthreads();                     // ... and every other wave's; stage 1 is free again
+                issue(1);
+                const bool more = kt + 2 < kt1;
+                if (more) warm();
+                multiply(0);
+                if (more) __builtin_amdgcn_s_waitcnt(0x0f71);
+                else __builtin_amdgcn_s_waitcnt(0x0f70);
+                __syncthreads();
+                if (more) {
+                    issue(0);
+                    if (kt + 3 < kt1) warm();
+                }
+                multiply(1);
             }
-            multiply(smem1);
-        }
-        if (kt < kt1) {
-            __builtin_amdgcn_s_waitcnt(0x0f70);
-            __syncthreads();
-            multiply(smem);
-        }
+            if (kt < kt1) {
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                __syncthreads();
+                multiply(0);
+            }
+        };
+        if (AKC && g.kscale != nullptr) run(std::true_type{});
+        else run(std::false_type{});
     } else if (interior) {
         const long k00 = klo + kt0 * BK;
         const char* pa = reinterpret_cast<const char*>(g.A) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
