@@ -128,7 +128,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
     int bi, bj;
     bool desc = false;  // walk the K range downwards (direct-to-LDS loop only; any order is correct)
-    if (g.xcd_rows) {
+    if (g.flags & GEMM_DIAG_BAND) {
+        // the diagonal 128x128 blocks of a LOWER product, three 64x64 tiles each (see gemm_impl)
+        const int d = tile / 3, q = tile - 3 * d;
+        bi = 2 * d + (q > 0);
+        bj = 2 * d + (q > 1);
+        if (bi >= g.tiles_m) return;
+    } else if (g.xcd_rows) {
         // Workgroup b runs on XCD b % 8.  For a tall-skinny output (few N tiles) give each XCD its own
         // M tiles and let that M tile's N tiles follow one another on it: the A rows are then fetched
         // into ONE L2 once instead of once per N tile from HBM / Infinity Cache.
@@ -158,10 +164,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             if (!(g.flags & GEMM_LOWER)) return;
             const int t = tile - ((g.nsuper + 7) / 8) * 512;
             if (t < 0) return;
-            const int d = t / 36, u = t % 36;
+            const bool strict = g.flags & GEMM_STRICT_LOWER;  // the diagonal tiles run in a launch of their own
+            const int per = strict ? 28 : 36;
+            const int d = t / per, u = t % per;
             int r = 0;
             while ((r + 1) * (r + 2) / 2 <= u) ++r;
-            bi = d * 8 + r;
+            bi = d * 8 + r + (strict ? 1 : 0);
             bj = d * 8 + (u - r * (r + 1) / 2);
             if (bi >= g.tiles_m) return;
         } else {
@@ -196,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             while (bi * (bi + 1) / 2 > tile) --bi;
             while ((bi + 1) * (bi + 2) / 2 <= tile) ++bi;
             bj = tile - bi * (bi + 1) / 2;
+            if (g.flags & GEMM_STRICT_LOWER) bi += 1;
         } else if (g.flags & (GEMM_KLO_M | GEMM_KHI_M)) {
             // K range depends on the M tile: neighbouring workgroups share it (same trip count, same A
             // rows in L2, marching through K together) when the N index runs fastest
@@ -600,6 +609,16 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     g.sq_n = (g.tiles_n + 7) / 8;
     g.nsuper = 0;
     long tail = 0;
+    // LOWER products with a full K range: T(T+1)/2 tiles of 128 overshoot a whole number of rounds of 512
+    // workgroups by T/2 (2080 = 4.06 rounds at 8192 rows: the launch paid for 5).  The main launch therefore
+    // takes the T(T-1)/2 tiles strictly below the diagonal (3.94 rounds) and a second, short launch the
+    // diagonal 128x128 blocks as three 64x64 tiles each (their upper right quarter is never needed).
+    const bool band = (flags & GEMM_LOWER) && !(flags & (GEMM_KLO_M | GEMM_KLO_N | GEMM_KHI_M | GEMM_KHI_N | GEMM_NO_BAND)) &&
+                      bt == 128 && g.splitk == 1 && g.tiles_m >= 32 && kscale == nullptr;
+    if (band) {
+        g.flags |= GEMM_STRICT_LOWER;
+        g.ntiles = g.tiles_m * (g.tiles_m - 1) / 2;
+    }
     {
         const int tri = flags & (GEMM_KLO_M | GEMM_KLO_N | GEMM_KHI_M | GEMM_KHI_N);
         const bool one_dep = tri == GEMM_KLO_M || tri == GEMM_KLO_N || tri == GEMM_KHI_M || tri == GEMM_KHI_N;
@@ -607,7 +626,7 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
         if (!(flags & GEMM_NO_SQUARES) && form_ok && bt == 128 && !g.xcd_rows && g.splitk == 1 && ((g.tiles_m >= 16 && (g.tiles_n >= 16 || g.tiles_n == 8)) || (flags & GEMM_FORCE_SQUARES))) {
             if (flags & GEMM_LOWER) {
                 g.nsuper = g.sq_m * (g.sq_m - 1) / 2;
-                tail = 36L * g.sq_m;
+                tail = (band ? 28L : 36L) * g.sq_m;
             } else {
                 g.nsuper = g.sq_m * g.sq_n;
             }
@@ -633,6 +652,16 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     }
     if (bt == 128) launch<4, 4>(st, a_kc, b_kc, g, (int)grid);
     else launch<2, 2>(st, a_kc, b_kc, g, (int)grid);
+    if (band) {
+        GemmArgs b = g;
+        b.flags = (g.flags & ~GEMM_STRICT_LOWER) | GEMM_DIAG_BAND;
+        b.nsuper = 0;
+        b.xcd_rows = 0;
+        const int t128 = g.tiles_m;
+        b.tiles_m = b.tiles_n = (int)((M + 63) / 64);
+        b.ntiles = 3 * t128;
+        launch<2, 2>(st, a_kc, b_kc, b, 3 * t128);
+    }
     if (g.splitk > 1) {
         const long tot = M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, C,

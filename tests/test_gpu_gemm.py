@@ -89,6 +89,26 @@ def test_gemm_square_tile_order_all_forms(n):
     assert np.max(np.abs(C - L.T @ E.T)) <= tol
 
 
+@pytest.mark.parametrize("n", [4096, 4096 + 70])
+@pytest.mark.parametrize("order", ["plain", "squares"])
+def test_gemm_lower_strict_launch_plus_diagonal_band(n, order):
+    """LOWER products of >= 32 tiles run as two launches: the tiles strictly below the diagonal, then the
+    diagonal 128 x 128 blocks as three 64 x 64 tiles each.  Together they must give every element of the
+    lower triangle, and nothing may be written 128 or more columns right of the diagonal."""
+    lib = _lib()
+    K = 192
+    rng = np.random.default_rng(n)
+    D = rng.uniform(-1, 1, (n, K))
+    C0 = rng.uniform(-1, 1, (n, n))
+    flags = lib.GEMM_LOWER | (lib.GEMM_FORCE_SQUARES if order == "squares" else 0)
+    C = lib.dgemm(D, D, C0, alpha=-1.0, beta=1.0, flags=flags)
+    ref = C0 - D @ D.T
+    assert np.max(np.abs(np.tril(C) - np.tril(ref))) <= 1e-13 * K
+    assert np.array_equal(np.triu(C, 128), np.triu(C0, 128))
+    C1 = lib.dgemm(D, D, C0, alpha=-1.0, beta=1.0, flags=flags | lib.GEMM_NO_BAND)   # one launch, as before
+    assert np.max(np.abs(np.tril(C1) - np.tril(ref))) <= 1e-13 * K
+
+
 def test_gemm_splitk_tall():
     lib = _lib()
     M, N, K = 96, 160, 40000
