@@ -26,6 +26,9 @@ struct DevBuf {
 
 struct gpx_ctx {
     int dev = 0;
+    // exact gradient path: the (buffer, n, lda) for which the upper triangle of W is known to be zero
+    const double* w_clean_p = nullptr;
+    long w_clean_n = 0, w_clean_lda = 0;
     hipStream_t st = nullptr;
     // side stream + events: the m x m factor chains of the sparse models run here, concurrently
     // with row-local work that does not depend on them (sparse.hip)
