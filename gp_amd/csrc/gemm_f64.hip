@@ -7,16 +7,21 @@
 //
 // Layout of one workgroup: 256 threads = 4 waves in a 2(M) x 2(N) grid, block tile
 // (32*TM) x (32*TN) with BK = 16; each wave owns TM x TN MFMA tiles of 16x16 (4x4 -> 64x64 per
-// wave, 128 accumulator VGPRs).  Operand tiles go global -> registers (prefetch of the next K
-// tile is in flight while the current one is multiplied) -> LDS -> one f64 per lane per MFMA.
+// wave, 128 accumulator VGPRs).  Three K loops, chosen per tile:
+//   1. interior 128x128 tiles: global -> LDS directly (global_load_lds_dwordx4 issued from inline
+//      assembly, two LDS stages, one barrier per K tile, explicit vmcnt waits, L2 warm-up load);
+//   2. other interior tiles: global -> registers (next K tile in flight during the MFMAs) -> LDS;
+//   3. edge tiles: the same with bounds tests.
 // The MFMA's "A" operand is fed from matrix B and its "B" operand from matrix A, so that the
 // lane index (lane & 15) runs along M: accumulator stores and the beta*C read are 128-B
 // contiguous per 16 lanes in the column-major C.
+// Tile order (blockIdx -> tile): split-K slabs (XCD-private when the slab count is a multiple of
+// 8), per-XCD rows for tall-skinny outputs, one 8x8 square of tiles per XCD with alternating K
+// direction for large outputs, LOWER products as a strictly-lower launch + a diagonal band launch.
 #include <array>
 #include <cstdlib>
 #include <type_traits>
 #include "gpx_internal.h"
-#include <cstdlib>
 
 namespace {
 
