@@ -103,3 +103,29 @@ def test_exact_mid_size_uses_the_128_tile_paths(gpx, n, d):
     assert np.max(np.abs(mu - mu_n)) <= 1e-9 * max(1.0, np.max(np.abs(mu_n)))
     assert np.max(np.abs(s2 - s2_n)) <= 1e-9 * max(1.0, np.max(np.abs(s2_n)))
     ctx.close()
+
+
+@pytest.mark.parametrize("model,n,m,d", [("fitc", 70000, 1024, 12), ("vfe", 66000, 1024, 12)])
+def test_sparse_mid_size_production_tile_orders(gpx, model, n, m, d):
+    """n >= 65536 rows with m = 1024 is where the sparse evaluation takes the tile orders of the full-size
+    runs: the 8x8 squares with alternating K direction on the tall triangular products (>= 64 squares),
+    XCD-private split-K slabs in a non-power-of-two count on the Gram products, the K-scale inside the
+    direct-to-LDS loop.  The scalar oracle would need minutes here; the independent NumPy / LAPACK closed
+    form (tests/np_gp.py, pinned to the oracle in tests/test_oracle.py) checks the same bars.  Inducing
+    points are separate draws in d = 12 with lengthscales halved (cond(Kuu) ~ 600; at d = 5 it is 4e8 and the
+    oracle and NumPy themselves disagree), so that conditioning does not blur the comparison."""
+    X, y, hyp, _ = synth.make_problem(7, n + m, d)
+    hyp = hyp.copy()
+    hyp[:d] -= 0.7
+    U, X, y = X[n:], X[:n], y[:n]
+    jit = 1e-6
+    M = gpx.MODEL_FITC if model == "fitc" else gpx.MODEL_VFE
+    fn = np_gp.fitc_nll if model == "fitc" else np_gp.vfe_nll
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    ctx.set_inducing(U)
+    nll, g = ctx.nll_grad(M, 0, hyp, jitter=jit)
+    nll_n, g_n = fn(0, X, y, U, jit, hyp)
+    assert abs(nll - nll_n) <= 1e-9 * max(1.0, abs(nll_n)), (nll, nll_n)
+    assert np.max(np.abs(g - g_n)) <= 1e-7 * max(1.0, np.max(np.abs(g_n))), (g, g_n)
+    ctx.close()
