@@ -94,6 +94,8 @@ def test_exact_mid_size_uses_the_128_tile_paths(gpx, n, d):
     ctx = gpx.Context()
     ctx.set_data(X, y)
     nll, g = ctx.nll_grad(gpx.MODEL_EXACT, 0, hyp)
+    nll2, g2 = ctx.nll_grad(gpx.MODEL_EXACT, 0, hyp)
+    assert nll2 == nll and np.array_equal(g2, g)     # tile orders, K directions and reductions are static: bit-identical reruns
     nll_n, g_n = np_gp.exact_nll(0, X, y, hyp)
     assert abs(nll - nll_n) <= 1e-9 * abs(nll_n)
     assert np.max(np.abs(g - g_n)) <= 1e-7 * max(1.0, np.max(np.abs(g_n)))
