@@ -1,0 +1,38 @@
+"""The JSON line of bench.py, as committed beside the rocprofv3 summary of the same command
+(profiles/r01h_default/bench.json), carries every field of the driver's contract plus the `roofline` and
+`cpu_baseline` objects, and its numbers are consistent with one another."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    with open(os.path.join(ROOT, "profiles", "r01h_default", "bench.json")) as f:
+        lines = [l for l in f.read().splitlines() if l.strip()]
+    assert len(lines) == 1            # stdout carries exactly one line
+    return json.loads(lines[0])
+
+
+def test_contract_fields():
+    d = _line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and "workload" in d["config"] and "model" not in d["config"]
+    assert "n=65536" in d["config"]["workload"] and "65536" in d["metric"]
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-9          # evals/s x s/eval
+
+
+def test_roofline_and_cpu_baseline_objects():
+    d = _line()
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.5 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    # the kernel-only rate bounds the end-to-end rate from above; both stay below the bare MFMA loop
+    assert d["algorithmic_tflops_per_gpu"] < r["achieved"] < d["measured_bare_mfma_f64_tflops"] <= 78.6 * 1.01
+    assert abs(r["algorithmic_flops_per_eval"] / 65536.0 ** 3 - 1.0) < 0.01   # n^3 flops per evaluation
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "evals/s" and c["value"] > 0 and "n=4096" in c["sample"]
