@@ -51,7 +51,11 @@ __global__ __launch_bounds__(256) void potrf_base_tile_kernel(double* __restrict
             for (int j = 0; j < 4; ++j) {
                 const double d = s[j][j];
                 bad = bad || !(d > 0.0);  // Eigen::LLT: NumericalIssue on a pivot <= 0
-                const double inv = 1.0 / d;
+                // 1/d on the critical path of the whole block: hardware reciprocal + two Newton steps (full
+                // precision to the last bit or two) instead of the IEEE division sequence
+                double inv = __builtin_amdgcn_rcp(d);
+                inv = fma(fma(-d, inv, 1.0), inv, inv);
+                inv = fma(fma(-d, inv, 1.0), inv, inv);
                 dvec[4 * p + j] = d;
                 invd[j] = inv;
                 double m[4];
