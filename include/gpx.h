@@ -39,11 +39,31 @@ int gpx_dgemm_kscale(int b_kc, int64_t M, int64_t N, int64_t K, double alpha, co
                      const double* kscale, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
                      int flags, double* work, int64_t work_doubles);
 
+/* No counterpart in the reference.  gpx_dgemm_splitk for callers that cannot allocate (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): the split-K slab workspace is a
+ * static device array of the library, GPX_NOALLOC_WORK_DOUBLES doubles (64 MiB) on every GPU the library
+ * runs on, held until the process ends.  Calls hipMalloc / hipFree never; the first call on a device looks
+ * the array's address up once (hipGetSymbolAddress).  Limit: M*N <= GPX_NOALLOC_MAX_MN output elements
+ * (e.g. the m = 1024 Gram product), larger sizes return 1 (GPX_ERR_ARG) with a message on stderr.  All
+ * calls on one GPU share the array: calls that overlap in time on one GPU race.  Runs on the NULL stream
+ * like gpx_dgemm_splitk and gives bit-identical results to it for a workspace of the same capacity. */
+#define GPX_NOALLOC_WORK_DOUBLES (8L * 1024 * 1024)
+#define GPX_NOALLOC_MAX_MN (1024L * 1024)
+int gpx_dgemm_splitk_noalloc(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+                             int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
+                             int flags);
 
 /* ---- measurement hooks (no reference counterpart) ------------------------------------------ */
-/* HIP-event timing of every GEMM launch with >= min_flops useful flops, on the launch stream. */
+/* HIP-event timing of every GEMM launch with >= min_flops useful flops, on the launch stream; a
+ * negative min_flops selects exactly the launches of the 128x128-tile kernel (the one bench.py's MFMA
+ * roofline object and the rocprofv3 --pmc traffic figure are about). */
 int gpx_prof_gemm_begin(double min_flops, int max_launches);
 int gpx_prof_gemm_end(double* total_ms, double* total_flops, int64_t* launches, double* skipped_flops);
+/* The same for the HBM-bound pairwise kernels: cls 0 = kernel-matrix builds (Cov::k, algorithmic bytes
+ * = 8 p q written, 4 n^2 for the lower-triangle-only build), cls 1 = the fused gradient trace pass
+ * (bytes = the weight matrices read); launches below min_bytes are left out. */
+int gpx_prof_pairwise_begin(double min_bytes, int max_launches);
+int gpx_prof_pairwise_end(int cls, double* total_ms, double* total_bytes, int64_t* launches);
 /* back-to-back v_mfma_f64_16x16x4_f64 from registers on every SIMD: the matrix pipe's ceiling */
 int gpx_bench_mfma_f64_peak(double* tflops);
 
