@@ -8,17 +8,24 @@ resident in HBM, fixed evaluation hypers.
   * headline (`value`): exact GP SE-ARD, n=65536 d=20 (BASELINE.json configs[2], the configuration
     the metric is quoted on).  The exact GP does not shard ("replicas only"): with --gpus N every
     rank runs one independent replica and `value` is their aggregate (weak scaling).
+  * `exact8192`: BASELINE.json configs[1] (n=8192 d=10), the launch-latency-bound size.
   * `fitc` (and `vfe` with --workload all|vfe): the sparse models with the training rows sharded
     over the N ranks and the m x m / m-vector partials summed by RCCL all-reduce (STRONG scaling:
-    n is fixed, BASELINE.json configs[3], [4]); reported in the same JSON line.
+    n is fixed, BASELINE.json configs[3], [4]); reported in the same JSON line with the RCCL world
+    size, per-rank times, the device time inside the two all-reduce hooks and the parallel efficiency
+    t_1 / (N t_N), t_1 measured in the same run on rank 0.
 
-Launch: `python bench.py` (N=1) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`.
-Prints ONE JSON line on rank 0.
+Launch: `python bench.py --gpus N` starts its own N ranks (one child process per GPU through
+`python -m torch.distributed.run`, started BEFORE this process touches the GPU; the parent only relays
+rank 0's JSON line).  Under an outer `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+(WORLD_SIZE already set) it is a worker.  Prints ONE JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,39 +39,177 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (public spec)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md)
 METRIC = "NLL+grad evals/sec: exact GP n=65536 d=20; FITC n=1M m=1024; % fp64 peak"
+PMC_DIRS = ("r02_pmc", "r01_pmc")   # newest committed rocprofv3 --pmc summary first
 
 
-def cpu_baseline_exact(d, n_sample, n_target):
-    """The oracle (a scalar single-thread C port of the reference's literal operation order) timed
-    on a bounded sample: one NLL+grad evaluation at n_sample, scaled by n^3 to the target n."""
+# ---- launcher: --gpus N > 1 without an outer torchrun ------------------------------------------------
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="default", choices=["default", "exact", "exact8192", "fitc", "vfe", "all"])
+    ap.add_argument("--n", type=int, default=65536)
+    ap.add_argument("--d", type=int, default=20)
+    ap.add_argument("--fitc-n", type=int, default=1 << 20)
+    ap.add_argument("--fitc-m", type=int, default=1024)
+    ap.add_argument("--vfe-n", type=int, default=1 << 22)
+    ap.add_argument("--vfe-m", type=int, default=2048)
+    ap.add_argument("--vfe-d", type=int, default=50)
+    ap.add_argument("--sparse-steps", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--predict-t", type=int, default=4096, help="test points of the exact-GP predict timing (0: skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the all-reduce hook (nccl == RCCL; gloo: rehearsal on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal: ranks map to GPU local_rank %% device_count (needs --backend gloo when ranks share a GPU)")
+    ap.add_argument("--no-t1", action="store_true", help="skip the single-GPU re-run behind parallel_efficiency")
+    ap.add_argument("--launch-dry", action="store_true",
+                    help="every rank prints its rank/world and exits before anything touches the GPU")
+    if argv is None and "GPX_BENCH_ARGV" in os.environ:
+        # a worker started by launch_children: the arguments travel in the environment, because
+        # torch.distributed.run's own parser claims abbreviations such as --d / --n (--duplicate-..., --nnodes)
+        argv = json.loads(os.environ["GPX_BENCH_ARGV"])
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_children(args):
+    """Parent of an N-rank run: never touches the GPU, never replaces its own image.  Starts the N workers
+    as CHILD processes and relays rank 0's JSON line (dry mode: one line listing every rank that reported)."""
+    if not args.launch_dry and not args.share_gpu:
+        import torch   # device_count() does not initialise the GPU on this image
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
+    env = dict(os.environ, GPX_BENCH_ARGV=json.dumps(sys.argv[1:]))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for line in proc.stdout:
+        line = line.strip()
+        if line.startswith("{"):
+            lines.append(line)
+        elif line:
+            print(line, file=sys.stderr)
+    rc = proc.wait()
+    if args.launch_dry:
+        ranks = [json.loads(l) for l in lines if '"launch_dry"' in l]
+        print(json.dumps({"launch_dry": True, "n_gpus": args.gpus, "launcher": "bench.py (child processes)",
+                          "ranks": sorted(r["rank"] for r in ranks), "worlds": sorted({r["world"] for r in ranks}),
+                          "local_ranks": sorted(r["local_rank"] for r in ranks)}), flush=True)
+        return rc
+    out = [l for l in lines if '"metric"' in l]
+    if rc == 0 and len(out) == 1:
+        print(out[0], flush=True)
+        return 0
+    print(f"bench.py: worker group failed (rc {rc}, {len(out)} result lines)", file=sys.stderr)
+    return rc or 1
+
+
+# ---- CPU baseline ---------------------------------------------------------------------------------------
+def _fit_power(ns, ts, power):
+    """least-squares a in t = a * n^power"""
+    x = np.asarray(ns, float) ** power
+    return float(np.dot(x, ts) / np.dot(x, x))
+
+
+def cpu_baseline(d, n_target, fitc_n, fitc_m):
+    """The oracle — a scalar C port of the reference's literal operation order (kind "port") — timed on the
+    GPU box's host cores on bounded samples of the same workloads: (i) 1 thread, as the
+    reference ships (CMakeLists.txt:12 has no OpenMP flag); (ii) the same file built with -fopenmp on every
+    core this process may use; measured points, the fitted a*n^3 (exact) / a*n (FITC) and the value
+    extrapolated to the benchmark size, labelled as such."""
     import oracle
     from gp_amd import synth
-    X, y, hyp, _ = synth.make_problem(2, n_sample, d)
-    t0 = time.perf_counter()
-    oracle.exact_nll(oracle.COV_SE_ARD, X, y, hyp)
-    dt = time.perf_counter() - t0
-    scale = (n_target / n_sample) ** 3
-    return {"value": 1.0 / (dt * scale), "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": f"1 NLL+grad eval of the exact GP at n={n_sample} d={d} took {dt:.2f} s on 1 host core "
-                      f"({1.0 / dt:.4f} evals/s); value is that scaled by ({n_sample}/{n_target})^3 to n={n_target} "
-                      f"(extrapolated; the reference as shipped is single-threaded, CMakeLists.txt:12)"}
+    cores = len(os.sched_getaffinity(0))
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or cores
+    X, y, hyp, _ = synth.make_problem(2, 4096, d)
+
+    def t_exact(fn, n):
+        t0 = time.perf_counter()
+        fn(oracle.COV_SE_ARD, X[:n], y[:n], hyp)
+        return time.perf_counter() - t0
+
+    one = {n: t_exact(oracle.exact_nll, n) for n in (1024, 2048, 3072)}          # ~1 + 5 + 16 s
+    a1 = _fit_power(list(one), list(one.values()), 3)
+    allc = {n: t_exact(oracle.exact_nll_all_cores, n) for n in (2048, 4096)}
+    aN = _fit_power(list(allc), list(allc.values()), 3)
+    out = {"value": 1.0 / (a1 * float(n_target) ** 3), "unit": "evals/s", "cores": 1, "kind": "port",
+           "host_cores_available": cores, "nproc": os.cpu_count(),
+           "sample": f"exact GP NLL+grad d={d}, 1 host thread, measured "
+                     + ", ".join(f"n={n}: {t:.2f} s" for n, t in one.items())
+                     + f"; least-squares t = a*n^3 with a = {a1:.3e} s; value = 1/(a*{n_target}^3) = extrapolated "
+                       f"{a1 * float(n_target) ** 3 / 3600:.1f} h per evaluation at n={n_target} "
+                       "(the reference as shipped is single-threaded, CMakeLists.txt:12; this scalar port runs at a few "
+                       "GFLOP/s, slower than the Eigen build it stands in for)",
+           "measured_s_1_thread": {str(n): t for n, t in one.items()},
+           "all_cores": {"value": 1.0 / (aN * float(n_target) ** 3), "unit": "evals/s", "cores": threads, "kind": "port",
+                         "sample": "same restatement built with -fopenmp (oracle/libgporacle_omp.so), measured "
+                                   + ", ".join(f"n={n}: {t:.2f} s" for n, t in allc.items())
+                                   + f"; fitted a = {aN:.3e} s, extrapolated to n={n_target}",
+                         "measured_s": {str(n): t for n, t in allc.items()}}}
+    # FITC, literal per-hyper loops (FITC.cpp:269-308: (2(d+1)+6) n m^2 flops): all cores only, the 1-thread
+    # run of even n = 4096 rows would take minutes
+    Xf, yf, hf, _ = synth.make_problem(3, 6144 + fitc_m, d)
+    U = Xf[:fitc_m]
+    pts = {}
+    for n in (2048, 4096):
+        t0 = time.perf_counter()
+        oracle.fitc_nll_all_cores(oracle.COV_SE_ARD, Xf[fitc_m:fitc_m + n], yf[fitc_m:fitc_m + n], U, 1e-8, hf)
+        pts[n] = time.perf_counter() - t0
+    a = _fit_power(list(pts), list(pts.values()), 1)   # the m x m work (two factors + inverses) is < 2 % of these samples
+    out["fitc_all_cores"] = {"value": 1.0 / (a * fitc_n), "unit": "evals/s", "cores": threads, "kind": "port",
+                             "sample": f"FITC NLL+grad m={fitc_m} d={d}, {threads} threads, measured "
+                                       + ", ".join(f"n={n}: {t:.2f} s" for n, t in pts.items())
+                                       + f"; least-squares t = a*n with a = {a:.3e} s, extrapolated to n={fitc_n}",
+                             "measured_s": {str(n): t for n, t in pts.items()}}
+    return out
 
 
+def trace(*a):
+    """GPX_BENCH_TRACE=1: stage markers on stderr, so that a hang in a multi-rank run names its stage"""
+    if os.environ.get("GPX_BENCH_TRACE") == "1":
+        print(f"[bench r{os.environ.get('RANK', '0')} {time.time() % 1000:.2f}]", *a, file=sys.stderr, flush=True)
+
+
+# ---- worker -----------------------------------------------------------------------------------------------
 class Dist:
     """torch.distributed (backend nccl == RCCL) only when WORLD_SIZE > 1."""
 
-    def __init__(self):
+    def __init__(self, args):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = self.local_rank
         self.torch = None
         self.dist = None
+        self.backend = None
+        self.hook_events = []
         if self.world > 1 or os.environ.get("GPX_BENCH_FORCE_DIST") == "1":
             import torch
             import torch.distributed as dist
-            torch.cuda.set_device(self.local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            if args.share_gpu:
+                self.device = self.local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(self.device)
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.device))
+            else:
+                dist.init_process_group("gloo")
+            self.backend = args.backend
             self.torch, self.dist = torch, dist
             self._views = {}
 
@@ -72,20 +217,37 @@ class Dist:
         """ENQUEUE the in-place sum all-reduce of `count` doubles at a raw device pointer on the
         library's own stream (RCCL over xGMI): torch sees that stream as an ExternalStream, the NCCL
         process group orders its collective after it and makes it wait for the result — the host
-        does not block, so the m x m chains that follow are queued ahead of the GPU."""
+        does not block, so the m x m chains that follow are queued ahead of the GPU.  A pair of events
+        on that stream brackets the collective (device time inside the hook, waiting for peers included)."""
         torch = self.torch
         key = (ptr, count, stream)
         hit = self._views.get(key)
         if hit is None:
             class _Mem:
                 __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-            ext = torch.cuda.ExternalStream(stream, device=torch.device("cuda", self.local_rank))
+            ext = torch.cuda.ExternalStream(stream, device=torch.device("cuda", self.device))
             with torch.cuda.stream(ext):
-                t = torch.as_tensor(_Mem(), device=torch.device("cuda", self.local_rank))
+                t = torch.as_tensor(_Mem(), device=torch.device("cuda", self.device))
             hit = self._views[key] = (ext, t)
         ext, t = hit
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(ext):
+            e0.record(ext)
             self.dist.all_reduce(t)
+            e1.record(ext)
+        self.hook_events.append((e0, e1, count))
+
+    def hook_stats(self, steps):
+        """ms per evaluation inside the hooks (device time between the bracketing events) and their sizes"""
+        if not self.hook_events:
+            return None
+        self.torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.hook_events)
+        counts = sorted({c for _, _, c in self.hook_events})
+        n = len(self.hook_events)
+        self.hook_events = []
+        return {"allreduce_ms_per_eval": ms / max(steps, 1), "allreduces_per_eval": n / max(steps, 1),
+                "allreduce_doubles": counts}
 
     def sync(self, lib):
         lib.check(lib.lib.gpx_device_synchronize(), "sync")
@@ -100,26 +262,43 @@ class Dist:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-
-def pmc_traffic(n):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE doubled as the gfx950 correction prescribes, + WRITE_SIZE; tools/pmc_bench.sh)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc", f"exact_n{n}_traffic.json")
-    if not os.path.exists(path):
-        return None
-    tot, cnt = 0.0, 0
-    for k, v in json.load(open(path)).items():
-        if k.startswith("gemm_kernel<4, 4"):
-            tot += (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"]) * v["launches"]
-            cnt += v["launches"]
-    return tot / cnt / 1e9 if cnt else None
+    def gather(self, x):
+        if self.dist is None:
+            return [x]
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
 
 
-def timed(D, lib, fn, steps, warmup, prof_min_flops):
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of the same
+    command (FETCH_SIZE corrected as the guide prescribes, + WRITE_SIZE; tools/pmc_bench.sh), averaged over
+    EVERY gemm_kernel<4,4,..> launch of an evaluation — the same launch set the live HIP-event timing of
+    `roofline` selects (gpx_prof_gemm_begin with a negative threshold = the 128x128-tile launches)."""
+    for dname in PMC_DIRS:
+        path = os.path.join(ROOT, "profiles", dname, "exact_n65536_traffic.json")
+        if not os.path.exists(path):
+            continue
+        tot, cnt = 0.0, 0
+        for k, v in json.load(open(path)).items():
+            if k.startswith("gemm_kernel<4, 4"):
+                tot += (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"]) * v["launches"]
+                cnt += v["launches"]
+        if cnt:
+            return tot / cnt / 1e9, cnt, dname
+    return None, None, None
+
+
+def timed(D, lib, fn, steps, warmup, prof_min_flops, pair_min_bytes=None):
     out = None
     for _ in range(warmup):
         out = fn()
-    lib.check(lib.lib.gpx_prof_gemm_begin(C.c_double(prof_min_flops), 8192), "prof_begin")
+    trace("warm-up done")
+    D.hook_events = []
+    lib.check(lib.lib.gpx_prof_gemm_begin(C.c_double(prof_min_flops), 16384), "prof_begin")
+    if pair_min_bytes is not None:
+        lib.check(lib.lib.gpx_prof_pairwise_begin(C.c_double(pair_min_bytes), 4096), "pair_prof_begin")
     D.sync(lib)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -130,14 +309,31 @@ def timed(D, lib, fn, steps, warmup, prof_min_flops):
     lib.check(lib.lib.gpx_prof_gemm_end(C.byref(ms_), C.byref(fl_), C.byref(nl_), C.byref(sk_)), "prof_end")
     prof = {"gemm_ms": ms_.value / steps, "gemm_flops": fl_.value / steps, "launches": int(nl_.value) // max(steps, 1),
             "small_flops": sk_.value / steps}
+    if pair_min_bytes is not None:
+        for cls, name in ((0, "cov_build"), (1, "pair_trace")):
+            by_ = C.c_double(0)
+            lib.check(lib.lib.gpx_prof_pairwise_end(cls, C.byref(ms_), C.byref(by_), C.byref(nl_)), "pair_prof_end")
+            prof[name] = {"ms": ms_.value / steps, "bytes": by_.value / steps, "launches": int(nl_.value) // max(steps, 1)}
+    prof["per_rank_ms"] = [1e3 * t / steps for t in D.gather(dt)]
     return D.max_over_ranks(dt), out, prof
 
 
-def run_exact(D, lib, synth, n, d, steps, warmup, predict_t):
-    X, y, hyp, Xs = synth.make_problem(2, n, d, max(predict_t, 1))
-    ctx = lib.Context(D.local_rank)
+def hbm_roofline(kernel, p, note):
+    """`roofline`-shaped object of one HBM-bound kernel: algorithmic bytes / live HIP-event duration"""
+    if not p or p["launches"] == 0 or p["ms"] <= 0:
+        return None
+    gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "traffic": None, "launches_per_eval": p["launches"],
+            "kernel_ms_per_eval": p["ms"], "algorithmic_bytes_per_eval": p["bytes"], "note": note}
+
+
+def run_exact(D, lib, synth, cfg, n, d, steps, warmup, predict_t, only128):
+    X, y, hyp, Xs = synth.make_problem(cfg, n, d, max(predict_t, 1))
+    ctx = lib.Context(D.device)
     ctx.set_data(X, y)
-    dt, (nll, g), prof = timed(D, lib, lambda: ctx.nll_grad(lib.MODEL_EXACT, lib.COV_SE_ARD, hyp), steps, warmup, 1e9)
+    dt, (nll, g), prof = timed(D, lib, lambda: ctx.nll_grad(lib.MODEL_EXACT, lib.COV_SE_ARD, hyp), steps, warmup,
+                               -1.0 if only128 else 1e9, 1e9)
     pred = None
     if predict_t > 0:
         # SURVEY 8(d) secondary metric: test points per second of _predict (mean + variance) after _setK;
@@ -157,43 +353,68 @@ def run_exact(D, lib, synth, n, d, steps, warmup, predict_t):
     return dt, nll, prof, pred
 
 
-def run_sparse(D, lib, synth, model, n, m, d, steps, warmup, cfg_index):
+def run_sparse(D, lib, synth, model, n, m, d, steps, warmup, cfg_index, want_t1):
     seed = 20240601 + cfg_index
     hyp = synth.eval_hyps(d)
     from gp_amd.sharding import shard_range
-    r0, r1 = shard_range(n, D.rank, D.world)
-    X = synth.make_inputs(seed, r1 - r0, d, start_point=r0)
-    y = synth.make_targets(seed, X, hyp, start_point=r0)
-    U = synth.make_inputs(seed, m, d, start_point=0)   # inducing points: the first m training points
-    ctx = lib.Context(D.local_rank)
-    ctx.set_data(X, y)
-    ctx.set_inducing(U)
-    if D.dist is not None:
-        ctx.set_allreduce_stream(D.allreduce_on_stream)
     M = lib.MODEL_FITC if model == "fitc" else lib.MODEL_VFE
     jitter = 1e-8   # (0.1 * noise_lb)^2 with the default noise_lb = 1e-3 (FITC.cpp:30, GP.cpp:28)
-    dt, (nll, g), prof = timed(D, lib, lambda: ctx.nll_grad(M, lib.COV_SE_ARD, hyp, jitter=jitter), steps, warmup, 1e8)
+    U = synth.make_inputs(seed, m, d, start_point=0)   # inducing points: the first m training points
+
+    def one(r0, r1, hooked):
+        X = synth.make_inputs(seed, r1 - r0, d, start_point=r0)
+        y = synth.make_targets(seed, X, hyp, start_point=r0)
+        ctx = lib.Context(D.device)
+        ctx.set_data(X, y)
+        ctx.set_inducing(U)
+        if hooked:
+            ctx.set_allreduce_stream(D.allreduce_on_stream)
+        return ctx
+
+    r0, r1 = shard_range(n, D.rank, D.world)
+    trace(model, "rows", r0, r1)
+    ctx = one(r0, r1, D.dist is not None)
+    trace(model, "context ready")
+    dt, (nll, g), prof = timed(D, lib, lambda: ctx.nll_grad(M, lib.COV_SE_ARD, hyp, jitter=jitter), steps, warmup, 1e8, 1e9)
+    trace(model, "timed", dt)
+    hook = D.hook_stats(steps)
     ctx.close()
-    return dt, nll, prof
+    trace(model, "hook stats", hook)
+    t1 = None
+    if D.world > 1 and want_t1:
+        # t_1 of parallel_efficiency = t_1 / (N t_N): the whole problem on rank 0's GPU alone, no hook,
+        # in the same run on the same machine; the other ranks wait at the barrier below
+        if D.rank == 0:
+            full = one(0, n, False)
+            full.nll_grad(M, lib.COV_SE_ARD, hyp, jitter=jitter)
+            lib.check(lib.lib.gpx_device_synchronize(), "sync")
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                nll1, _ = full.nll_grad(M, lib.COV_SE_ARD, hyp, jitter=jitter)
+            lib.check(lib.lib.gpx_device_synchronize(), "sync")
+            t1 = (time.perf_counter() - t0) / steps
+            full.close()
+            if not abs(nll1 - nll) <= 1e-9 * abs(nll1):
+                raise RuntimeError(f"{model}: sharded NLL {nll!r} differs from the single-GPU NLL {nll1!r}")
+        trace(model, "t1", t1)
+        D.sync(lib)
+    return dt, nll, prof, hook, t1
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="default", choices=["default", "exact", "fitc", "vfe", "all"])
-    ap.add_argument("--n", type=int, default=65536)
-    ap.add_argument("--d", type=int, default=20)
-    ap.add_argument("--fitc-n", type=int, default=1 << 20)
-    ap.add_argument("--fitc-m", type=int, default=1024)
-    ap.add_argument("--vfe-n", type=int, default=1 << 22)
-    ap.add_argument("--vfe-m", type=int, default=2048)
-    ap.add_argument("--vfe-d", type=int, default=50)
-    ap.add_argument("--sparse-steps", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--predict-t", type=int, default=4096, help="test points of the exact-GP predict timing (0: skip)")
-    args = ap.parse_args()
+    args = parse_args()
+    in_group = "WORLD_SIZE" in os.environ or "RANK" in os.environ
+    if args.launch_dry and in_group:
+        print(json.dumps({"launch_dry": True, "rank": int(os.environ.get("RANK", "0")),
+                          "world": int(os.environ.get("WORLD_SIZE", "1")),
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}), flush=True)
+        return 0
+    if args.gpus > 1 and not in_group:
+        return launch_children(args)
+    if args.launch_dry:
+        print(json.dumps({"launch_dry": True, "n_gpus": 1, "launcher": "none (single process)", "ranks": [0],
+                          "worlds": [1], "local_ranks": [0]}), flush=True)
+        return 0
 
     # stdout carries exactly ONE line, the JSON: anything a library prints there meanwhile (RCCL's
     # version banner on the first collective) goes to stderr instead
@@ -201,50 +422,90 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    D = Dist()
+    trace("worker start")
+    D = Dist(args)
+    trace("process group ready")
     from gp_amd import lib, synth
-    want = {"default": ("exact", "fitc"), "all": ("exact", "fitc", "vfe")}.get(args.workload, (args.workload,))
+    lib.lib.gpx_prof_pairwise_begin.argtypes = [C.c_double, C.c_int]
+    lib.lib.gpx_prof_pairwise_end.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    want = {"default": ("exact", "exact8192", "fitc"), "all": ("exact", "exact8192", "fitc", "vfe")}.get(args.workload, (args.workload,))
     out = {"metric": METRIC, "unit": "evals/s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
            "higher_is_better": True, "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+    if D.dist is not None:
+        out["rccl_world_size"] = D.dist.get_world_size()
+        out["collective_backend"] = "rccl (torch.distributed nccl)" if D.backend == "nccl" else "gloo (rehearsal, not xGMI)"
 
     if "exact" in want:
         n, d = args.n, args.d
-        dt, nll, prof, pred = run_exact(D, lib, synth, n, d, args.steps, args.warmup, args.predict_t)
+        dt, nll, prof, pred = run_exact(D, lib, synth, 2, n, d, args.steps, args.warmup, args.predict_t, True)
         evals = args.steps * D.world
         gemm_tf = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] > 0 else 0.0
         alg_tf = float(n) ** 3 * args.steps / dt / 1e12   # per GPU
+        traffic, traffic_launches, traffic_src = pmc_traffic() if n == 65536 else (None, None, None)
         out.update({
             "value": evals / dt, "ms_per_step": 1e3 * dt / args.steps, "scaling": "weak",
             "config": {"workload": f"exact GP SE-ARD NLL+grad, n={n} d={d} (BASELINE configs[2]); "
                                    f"{D.world} independent replica(s), one per GPU", "n": n, "d": d,
                        "parallelism": "replicas" if D.world > 1 else "single"},
             "nll": nll, "algorithmic_tflops_per_gpu": alg_tf, "frac_fp64_peak_whole_eval": alg_tf / FP64_MFMA_PEAK_TFLOPS,
+            "per_rank_ms": prof["per_rank_ms"],
             "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gemm_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(n),
-                         "traffic_unit": "GB per launch (L2-miss bytes incl. Infinity-Cache hits; separate --pmc passes, profiles/r01_pmc)",
-                         "kernel": "gemm_kernel<4,4,*,*> (fp64 MFMA GEMM/SYRK/TRMM tiles; all launches >= 1 GFLOP)",
+                         "frac": gemm_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "GB per launch, mean over the gemm_kernel<4,4,..> launches of one evaluation "
+                                         "(L2-miss bytes incl. Infinity-Cache hits; separate --pmc passes)",
+                         "traffic_launches_per_eval": traffic_launches, "traffic_source": traffic_src and f"profiles/{traffic_src}",
+                         "kernel": "gemm_kernel<4,4,*,*> (fp64 MFMA GEMM/SYRK/TRMM, 128x128 tiles): every launch of it",
                          "launches_per_eval": prof["launches"], "kernel_ms_per_eval": prof["gemm_ms"],
                          "algorithmic_flops_per_eval": prof["gemm_flops"],
-                         "flops_in_untimed_small_launches_per_eval": prof["small_flops"]},
+                         "flops_in_other_gemm_launches_per_eval": prof["small_flops"]},
+            "hbm_rooflines": [r for r in (
+                hbm_roofline("cov_build_kernel (K + sn2 I, lower triangle)", prof.get("cov_build"),
+                             "algorithmic bytes = 4 n^2 written; VALU-bound (exp + direct differences), DESIGN.md §3.3"),
+                hbm_roofline("pair_trace_kernel (fused gradient trace over (K+sn2 I)^-1)", prof.get("pair_trace"),
+                             "algorithmic bytes = 4 n^2 read")) if r],
         })
         if pred is not None:
             out["predict"] = pred
+    if "exact8192" in want:
+        n, d = 8192, 10
+        st = max(args.steps, 10)
+        dt, nll, prof, _ = run_exact(D, lib, synth, 1, n, d, st, 2, 0, False)
+        tf = float(n) ** 3 * st / dt / 1e12
+        sub = {"value": st * D.world / dt, "unit": "evals/s", "ms_per_step": 1e3 * dt / st, "steps": st,
+               "config": {"workload": f"exact GP SE-ARD NLL+grad, n={n} d={d} (BASELINE configs[1])", "n": n, "d": d},
+               "nll": nll, "algorithmic_tflops_per_gpu": tf, "frac_fp64_peak_whole_eval": tf / FP64_MFMA_PEAK_TFLOPS}
+        out["exact8192"] = sub
+        if "value" not in out:
+            out.update({"value": sub["value"], "ms_per_step": sub["ms_per_step"], "scaling": "weak", "config": sub["config"],
+                        "steps": st})
     for model in ("fitc", "vfe"):
         if model not in want:
             continue
         n, m, d = (args.fitc_n, args.fitc_m, args.d) if model == "fitc" else (args.vfe_n, args.vfe_m, args.vfe_d)
-        dt, nll, prof = run_sparse(D, lib, synth, model, n, m, d, args.sparse_steps, 1, 3 if model == "fitc" else 4)
+        dt, nll, prof, hook, t1 = run_sparse(D, lib, synth, model, n, m, d, args.sparse_steps, 1, 3 if model == "fitc" else 4,
+                                             not args.no_t1)
         flops = (6.0 if model == "fitc" else 3.0) * n * m * m
         tf = flops * args.sparse_steps / dt / 1e12
+        gemm_tf = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] > 0 else 0.0
         sub = {"value": args.sparse_steps / dt, "unit": "evals/s", "ms_per_step": 1e3 * dt / args.sparse_steps,
                "scaling": "strong", "n_gpus": D.world, "steps": args.sparse_steps,
                "config": {"workload": f"{model.upper()} SE-ARD NLL+grad, n={n} m={m} d={d}, rows sharded over "
                                       f"{D.world} GPU(s), RCCL all-reduce of m x m partials", "n": n, "m": m, "d": d},
                "nll": nll, "algorithmic_tflops_total": tf,
                "frac_fp64_peak_per_gpu": tf / D.world / FP64_MFMA_PEAK_TFLOPS,
-               "gemm_ms_per_eval_rank0": prof["gemm_ms"]}
+               "per_rank_ms": prof["per_rank_ms"],
+               "gemm_ms_per_eval_rank0": prof["gemm_ms"], "gemm_tflops_rank0": gemm_tf,
+               "hbm_rooflines": [r for r in (
+                   hbm_roofline("Kxu build (cov_build / cov_mfma kernel)", prof.get("cov_build"), "algorithmic bytes = 8 n m written"),
+                   hbm_roofline("fused gradient trace over W_xu (pair_trace kernel)", prof.get("pair_trace"),
+                                "algorithmic bytes = the n x m weight matrices read (2 for FITC, 1 for VFE)")) if r]}
+        if hook:
+            sub.update(hook)
+        if t1 is not None:
+            sub["t1_ms_single_gpu_same_run"] = 1e3 * t1
+            sub["parallel_efficiency"] = t1 / (D.world * dt / args.sparse_steps)
         out[model] = sub
-        if "exact" not in want and "value" not in out:
+        if "value" not in out:
             out.update({"value": sub["value"], "ms_per_step": sub["ms_per_step"], "scaling": "strong",
                         "config": sub["config"], "steps": args.sparse_steps})
 
@@ -256,12 +517,14 @@ def main():
             best = max(best, peak.value)
         out["measured_bare_mfma_f64_tflops"] = best   # register-operand MFMA loop, 16 accumulators, 2 waves/SIMD
         if not args.no_cpu_baseline and D.world == 1 and "exact" in want:
-            out["cpu_baseline"] = cpu_baseline_exact(args.d, min(4096, args.n), args.n)  # ~20 s of CPU work
+            out["cpu_baseline"] = cpu_baseline(args.d, args.n, args.fitc_n, args.fitc_m)   # ~45 s of CPU work
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if D.dist is not None:
+        D.dist.barrier()
         D.dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -77,5 +77,13 @@ int gpx_prof_gemm_end(double* total_ms, double* total_flops, int64_t* launches, 
     return rc;
 }
 int gpx_bench_mfma_f64_peak(double* tflops) { return gpx_mfma_peak(tflops); }
+int gpx_prof_pairwise_begin(double min_bytes, int max_launches) { return gpx_pair_prof_begin(min_bytes, max_launches); }
+int gpx_prof_pairwise_end(int cls, double* total_ms, double* total_bytes, int64_t* launches) {
+    if (!total_ms || !total_bytes || !launches || (cls != 0 && cls != 1)) return GPX_ERR_ARG;
+    long l = 0;
+    const int rc = gpx_pair_prof_end(cls, total_ms, total_bytes, &l);
+    *launches = l;
+    return rc;
+}
 
 }  // extern "C"

@@ -20,6 +20,7 @@
 // direction for large outputs, LOWER products as a strictly-lower launch + a diagonal band launch.
 #include <array>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include "gpx_internal.h"
 #include "tile_order.h"
@@ -444,7 +445,9 @@ void launch(hipStream_t st, int a_kc, int b_kc, const GemmArgs& g, int grid) {
 
 // ---- optional per-launch HIP-event timing of the large GEMMs (bench.py's roofline leg) -------
 struct GemmProf {
+    std::mutex mu;  // contexts on different host threads launch GEMMs concurrently
     bool on = false;
+    bool only128 = false;  // time the 128x128-tile launches only (the kernel the roofline object names)
     double min_flops = 0;
     std::vector<hipEvent_t> ev;  // pairs
     std::vector<double> flops;
@@ -495,10 +498,16 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     if (grid > 0x7fffffffL) return GPX_ERR_ARG;
     const double fl = useful_flops(M, N, K, flags);
     bool timed = false;
+    size_t slot = 0;
     if (g_prof.on) {
-        if (fl >= g_prof.min_flops && g_prof.used + 2 <= g_prof.ev.size()) {
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (g_prof.on && fl >= g_prof.min_flops && (!g_prof.only128 || bt == 128) && g_prof.used + 2 <= g_prof.ev.size()) {
             timed = true;
-            (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+            slot = g_prof.used;
+            g_prof.used += 2;
+            g_prof.flops.push_back(fl);
+            g_prof.shape.push_back({M, N, K, (long)a_kc, (long)b_kc, (long)flags});
+            (void)hipEventRecord(g_prof.ev[slot], st);
         } else {
             g_prof.skipped_flops += fl;
             g_prof.skipped++;
@@ -517,12 +526,7 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
                            ldc, work, g.slab, g.splitk, (int)M, (int)N, beta,
                            (flags & GEMM_LOWER) ? bt : 0);
     }
-    if (timed) {
-        (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
-        g_prof.flops.push_back(fl);
-        g_prof.shape.push_back({M, N, K, (long)a_kc, (long)b_kc, (long)flags});
-        g_prof.used += 2;
-    }
+    if (timed) (void)hipEventRecord(g_prof.ev[slot + 1], st);
     HIP_TRY(hipGetLastError());
     return GPX_OK;
 }
@@ -553,6 +557,9 @@ __global__ __launch_bounds__(256, 2) void mfma_peak_kernel(double* out, int iter
 }  // namespace
 
 int gpx_gemm_prof_begin(double min_flops, int max_launches) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.only128 = min_flops < 0;  // negative threshold: "every 128x128-tile launch, nothing else"
+    if (min_flops < 0) min_flops = 0;
     if (g_prof.ev.size() < (size_t)max_launches * 2) {
         const size_t old = g_prof.ev.size();
         g_prof.ev.resize((size_t)max_launches * 2);
@@ -569,6 +576,7 @@ int gpx_gemm_prof_begin(double min_flops, int max_launches) {
 }
 
 int gpx_gemm_prof_end(double* total_ms, double* total_flops, long* launches, double* skipped_flops) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.on = false;
     double ms = 0, fl = 0;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {

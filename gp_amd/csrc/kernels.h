@@ -27,6 +27,9 @@ int gpx_cov_build(hipStream_t st, const double* Xt1, long ld1, long p, const dou
 // out[0..d-1] = S_i, out[d] = sum w K, out[d+1] = tr(w); partial_ws >= 2048*66 doubles
 int gpx_pair_trace(hipStream_t st, TraceArgs g, int d, double* partial_ws, long ws_doubles, double* out);
 #define GPX_TRACE_WS (2048L * 66)
+// HIP-event timing of cov_build (cls 0) / pair_trace (cls 1) launches that move >= min_bytes algorithmic bytes
+int gpx_pair_prof_begin(double min_bytes, int max_launches);
+int gpx_pair_prof_end(int cls, double* total_ms, double* total_bytes, long* launches);
 
 // ---- chol.hip -------------------------------------------------------------------------------
 // Blocked recursive lower Cholesky in place (lower triangle of A).  Wd (64 x roundup(n,64),

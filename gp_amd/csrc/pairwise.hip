@@ -14,9 +14,36 @@
 // first index so every global access is a contiguous 512-B row per wave.
 #include "gpx_internal.h"
 #include "kernels.h"
+#include <mutex>
 #include <type_traits>
 
 namespace {
+
+// ---- optional HIP-event timing of the large pairwise launches (bench.py's HBM roofline objects) ----
+struct PairProf {
+    std::mutex mu;
+    bool on = false;
+    double min_bytes = 0;
+    std::vector<hipEvent_t> ev;  // pairs
+    std::vector<double> bytes;
+    std::vector<int> cls;  // 0 = cov_build, 1 = pair_trace
+    size_t used = 0;
+} p_prof;
+
+long pp_open(hipStream_t st, int cls, double bytes) {
+    if (!p_prof.on) return -1;
+    std::lock_guard<std::mutex> lk(p_prof.mu);
+    if (!p_prof.on || bytes < p_prof.min_bytes || p_prof.used + 2 > p_prof.ev.size()) return -1;
+    const long slot = (long)p_prof.used;
+    p_prof.used += 2;
+    p_prof.bytes.push_back(bytes);
+    p_prof.cls.push_back(cls);
+    (void)hipEventRecord(p_prof.ev[slot], st);
+    return slot;
+}
+void pp_close(hipStream_t st, long slot) {
+    if (slot >= 0) (void)hipEventRecord(p_prof.ev[slot + 1], st);
+}
 
 constexpr int DCH = 32;  // dimensions staged in LDS at a time
 
@@ -335,8 +362,10 @@ int gpx_cov_build(hipStream_t st, const double* Xt1, long ld1, long p, const dou
     const long ntiles = lower ? tp * (tp + 1) / 2 : tp * tq;
     if (ntiles > 0x7fffffffL) return GPX_ERR_ARG;
     const int vec = ((reinterpret_cast<uintptr_t>(out) & 15) == 0 && ldo % 2 == 0) ? 1 : 0;
+    const long slot = pp_open(st, 0, lower ? 4.0 * (double)p * (double)(p + 1) : 8.0 * (double)p * (double)q);
     hipLaunchKernelGGL(cov_build_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, Xt1, ld1, p, Xt2, ld2, q,
                        dpad, sf2, out, ldo, lower, (int)tp, diag_add, vec);
+    pp_close(st, slot);
     HIP_TRY(hipGetLastError());
     return GPX_OK;
 }
@@ -355,6 +384,7 @@ int gpx_pair_trace(hipStream_t st, TraceArgs g, int d, double* partial_ws, long 
     // up to 32 dimensions per pass in registers, plus up to 32 more in LDS accumulators when there are
     // more: d <= 64 is ONE pass over the weights
     const int dc = g.dpad <= 8 ? 8 : g.dpad <= 16 ? 16 : g.dpad <= 24 ? 24 : 32;
+    const long slot = pp_open(st, 1, (g.sym ? 4.0 * (double)g.p * (double)(g.p + 1) : 8.0 * (double)g.p * (double)g.q) * (g.M2 ? 2.0 : 1.0));
     for (int dim0 = 0; dim0 < g.dpad; dim0 += 64) {
         const int rest = g.dpad - dim0;
         const int dl = rest <= 32 ? 0 : rest <= 48 ? 16 : rest <= 56 ? 24 : 32;  // (a DL = 8 instance spills)
@@ -381,6 +411,42 @@ int gpx_pair_trace(hipStream_t st, TraceArgs g, int d, double* partial_ws, long 
         hipLaunchKernelGGL(trace_finish_kernel, dim3(width), dim3(256), 0, st, partial_ws, (int)nwg, width, dim0,
                            dc + dl, d, dim0 == 0 ? 1 : 0, out);
     }
+    pp_close(st, slot);
     HIP_TRY(hipGetLastError());
+    return GPX_OK;
+}
+
+int gpx_pair_prof_begin(double min_bytes, int max_launches) {
+    std::lock_guard<std::mutex> lk(p_prof.mu);
+    if (p_prof.ev.size() < (size_t)max_launches * 2) {
+        const size_t old = p_prof.ev.size();
+        p_prof.ev.resize((size_t)max_launches * 2);
+        for (size_t i = old; i < p_prof.ev.size(); ++i) HIP_TRY(hipEventCreate(&p_prof.ev[i]));
+    }
+    p_prof.on = true;
+    p_prof.min_bytes = min_bytes;
+    p_prof.used = 0;
+    p_prof.bytes.clear();
+    p_prof.cls.clear();
+    return GPX_OK;
+}
+
+int gpx_pair_prof_end(int cls, double* total_ms, double* total_bytes, long* launches) {
+    std::lock_guard<std::mutex> lk(p_prof.mu);
+    p_prof.on = false;
+    double ms = 0, by = 0;
+    long cnt = 0;
+    for (size_t i = 0; i + 1 < p_prof.used; i += 2) {
+        if (p_prof.cls[i / 2] != cls) continue;
+        HIP_TRY(hipEventSynchronize(p_prof.ev[i + 1]));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, p_prof.ev[i], p_prof.ev[i + 1]));
+        ms += t;
+        by += p_prof.bytes[i / 2];
+        ++cnt;
+    }
+    *total_ms = ms;
+    *total_bytes = by;
+    *launches = cnt;
     return GPX_OK;
 }

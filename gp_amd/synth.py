@@ -56,7 +56,7 @@ def make_targets(seed, X, hyp, n_features=256, chunk=1 << 18, start_point=0):
         e = min(n, s + chunk)
         y[s:e] = np.cos(X[s:e] @ w.T + b).sum(axis=1)
     y *= sf * np.sqrt(2.0 / n_features)
-    y += mean + sn * _normal(seed ^ 0xA11CE, start_point, n)
+    y += mean + sn * _normal(seed ^ 0xA11CE, 2 * start_point, n)   # Box-Muller: two uniforms per point
     return y
 
 

@@ -190,3 +190,39 @@ class SparseState:
         if getattr(self, "_h", None):
             _lib.orc_sparse_free(self._h)
             self._h = None
+
+
+# ---- the OpenMP build of the SAME restatement: bench.py's "all host cores" CPU timing only ---------
+_SO_OMP = os.path.join(_HERE, "libgporacle_omp.so")
+_omp = None
+
+
+def _load_omp():
+    global _omp
+    if _omp is None:
+        if not os.path.exists(_SO_OMP):
+            build()
+        _omp = C.CDLL(_SO_OMP)
+        _omp.orc_exact_nll.argtypes = _lib.orc_exact_nll.argtypes
+        _omp.orc_exact_nll.restype = _d
+        for name in ("orc_fitc_nll", "orc_vfe_nll"):
+            getattr(_omp, name).argtypes = _lib.orc_fitc_nll.argtypes
+            getattr(_omp, name).restype = _d
+    return _omp
+
+
+def exact_nll_all_cores(cov, X, y, hyp):
+    """exact_nll from libgporacle_omp.so (thread count: OMP_NUM_THREADS, else every core the process may use)."""
+    lib = _load_omp()
+    X, y, hyp = _f(X), _f(y), _f(hyp)
+    n, d = X.shape
+    g = np.zeros(len(hyp))
+    return lib.orc_exact_nll(cov, d, n, _p(X), _p(y), _p(hyp), 1, _p(g)), g
+
+
+def fitc_nll_all_cores(cov, X, y, U, jitter, hyp):
+    return _sparse_nll(_load_omp().orc_fitc_nll, cov, X, y, U, jitter, hyp, True)
+
+
+def vfe_nll_all_cores(cov, X, y, U, jitter, hyp):
+    return _sparse_nll(_load_omp().orc_vfe_nll, cov, X, y, U, jitter, hyp, True)

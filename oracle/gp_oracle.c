@@ -17,6 +17,19 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+/* The reference is single-threaded (CMakeLists.txt:12 has no -fopenmp) and so is libgporacle.so.  The
+ * same file built with -fopenmp (libgporacle_omp.so, `make omp`) spreads the independent columns /
+ * right-hand sides of the O(n^3), O(n m^2) and O(n^2 d) loops over the host cores: that build exists
+ * only for bench.py's "all host cores" CPU timing; every parity test uses the serial build. */
+#ifdef _OPENMP
+#define OMP_PRAGMA(x) _Pragma(#x)
+#define OMP_FOR OMP_PRAGMA(omp parallel for schedule(static))
+#define OMP_FOR_IF(c) OMP_PRAGMA(omp parallel for schedule(static) if (c))
+#else
+#define OMP_FOR
+#define OMP_FOR_IF(c)
+#endif
+
 static double* dnew(size_t n) {
     double* p = (double*)calloc(n ? n : 1, sizeof(double));
     if (!p) abort();
@@ -28,6 +41,7 @@ static int sf_index(int cov, int d) { return cov == ORC_COV_SE_ARD ? d : 1; }
 
 /* util.cpp:64-75: dists.col(i) = sdist_vm(Y.col(i), X) = (X.colwise() - y_i).colwise().squaredNorm() */
 void orc_sdist_mm(int d, const double* X, long p, const double* Y, long q, double* D) {
+    OMP_FOR
     for (long b = 0; b < q; ++b) {
         const double* yb = Y + (size_t)b * d;
         double* col = D + (size_t)b * p;
@@ -66,6 +80,7 @@ void orc_cov_k(int cov, int d, const double* hyp, const double* x1, long p, cons
     double* s2 = scaled_inputs(cov, d, hyp, x2, q);
     orc_sdist_mm(d, s1, p, s2, q, K);
     const double sf2 = exp(2 * hyp[sf_index(cov, d)]);
+    OMP_FOR
     for (size_t e = 0; e < (size_t)p * q; ++e) K[e] = sf2 * exp(-0.5 * K[e]);
     free(s1);
     free(s2);
@@ -77,6 +92,7 @@ void orc_cov_dk_dhyp(int cov, int d, const double* hyp, int idx, const double* x
     if (cov == ORC_COV_SE_ARD) {
         if (idx < d) {
             const double l_inv = exp(-1 * hyp[idx]);
+            OMP_FOR
             for (long b = 0; b < q; ++b) {
                 const double xb = l_inv * x2[(size_t)b * d + idx];
                 for (long a = 0; a < p; ++a) {
@@ -214,6 +230,7 @@ int orc_chol(double* A, long n) {
         const double ljj = sqrt(piv);
         cj[j] = ljj;
         for (long i = j + 1; i < n; ++i) cj[i] /= ljj;
+        OMP_FOR_IF(n - j > 128)
         for (long k = j + 1; k < n; ++k) {
             const double lkj = cj[k];
             double* ck = A + (size_t)k * n;
@@ -225,6 +242,7 @@ int orc_chol(double* A, long n) {
 
 /* solve: L L^T x = b by forward then backward substitution, one right-hand side at a time */
 void orc_chol_solve(const double* L, long n, double* B, long nrhs) {
+    OMP_FOR_IF(nrhs > 1)
     for (long r = 0; r < nrhs; ++r) {
         double* b = B + (size_t)r * n;
         for (long j = 0; j < n; ++j) {
@@ -495,6 +513,7 @@ void orc_exact_predict(const orc_exact_state* st, const double* Xs, long t, doub
 /* C[m x n] = A[m x k] * B[k x n] */
 static void gemm_nn(long m, long n, long k, const double* A, const double* B, double* C) {
     memset(C, 0, sizeof(double) * (size_t)m * n);
+    OMP_FOR_IF(n > 1)
     for (long j = 0; j < n; ++j)
         for (long l = 0; l < k; ++l) {
             const double b = B[(size_t)j * k + l];

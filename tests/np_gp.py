@@ -17,8 +17,32 @@ def split_hyp(cov, d, hyp):
     return nk, ell, np.exp(2 * hyp[nk - 1]), np.exp(2 * hyp[nk]), hyp[nk + 1]
 
 
+class _LeanSqd:
+    """Stand-in for the (d, p, q) array of sqd_per_dim when that array would not fit in memory (the
+    benchmark's own shapes: n x m x d = 66000 x 2048 x 50): the same direct differences, one dimension
+    at a time, p x q temporaries only."""
+
+    def __init__(self, X1, X2, ell):
+        self.a = np.ascontiguousarray((X1 / ell).T)
+        self.b = np.ascontiguousarray((X2 / ell).T)
+
+    def dim(self, i):
+        t = self.a[i][:, None] - self.b[i][None, :]
+        t *= t
+        return t
+
+    def sum(self, axis=0):
+        assert axis == 0
+        s = self.dim(0)
+        for i in range(1, len(self.a)):
+            s += self.dim(i)
+        return s
+
+
 def sqd_per_dim(X1, X2, ell):
-    """(d, p, q) array of ((x1_i - x2_i)/l_i)^2"""
+    """(d, p, q) array of ((x1_i - x2_i)/l_i)^2 (a lazy per-dimension object above 2e8 elements)"""
+    if X1.shape[0] * X2.shape[0] * X1.shape[1] > 2e8:
+        return _LeanSqd(X1, X2, ell)
     a = (X1 / ell).T[:, :, None]
     b = (X2 / ell).T[:, None, :]
     return (a - b) ** 2
@@ -33,7 +57,10 @@ def cov_k(cov, hyp, X1, X2):
 def _kernel_grad_sums(cov, W, K, D):
     """sum_ab W_ab dK_ab/dtheta_i for every kernel hyper, K and D = sqd_per_dim given."""
     WK = W * K
-    per_dim = (WK[None] * D).sum(axis=(1, 2))
+    if isinstance(D, _LeanSqd):
+        per_dim = np.array([np.sum(WK * D.dim(i)) for i in range(len(D.a))])
+    else:
+        per_dim = (WK[None] * D).sum(axis=(1, 2))
     if cov == ARD:
         return np.concatenate([per_dim, [2 * WK.sum()]])
     return np.array([per_dim.sum(), 2 * WK.sum()])

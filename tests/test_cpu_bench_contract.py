@@ -36,3 +36,28 @@ def test_roofline_and_cpu_baseline_objects():
     assert abs(r["algorithmic_flops_per_eval"] / 65536.0 ** 3 - 1.0) < 0.01   # n^3 flops per evaluation
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "evals/s" and c["value"] > 0 and "n=4096" in c["sample"]
+
+
+def test_bench_gpus_n_starts_n_distinct_ranks_before_any_gpu_call():
+    """`python bench.py --gpus N` (the driver's command shape, no outer torchrun) must produce N ranks by itself:
+    --launch-dry makes every child report rank/world and exit before gp_amd.lib or torch.cuda is imported."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-dry"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["launch_dry"] and d["n_gpus"] == 3 and d["ranks"] == [0, 1, 2] and d["worlds"] == [3] and d["local_ranks"] == [0, 1, 2]
+
+
+def test_bench_worker_under_an_outer_launcher_does_not_spawn_again():
+    """under torch.distributed.run (WORLD_SIZE set) bench.py is a worker: one dry line per rank, no nested launch"""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="4", RANK="2", LOCAL_RANK="2")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-dry"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip()) == {"launch_dry": True, "rank": 2, "world": 4, "local_rank": 2}

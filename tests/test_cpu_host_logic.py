@@ -59,3 +59,21 @@ def test_dense_stand_ins_are_column_major(res):
     assert f(res["dense_colmajor"]).tolist() == [10, 1, 12]
     assert f(res["dense_transpose"]).tolist() == [3, 2, 12] and f(res["dense_col"]).tolist() == [2, 12]
     assert f(res["dense_blocks"]).tolist() == [11, 12]
+
+
+def test_synthetic_shards_concatenate_to_the_full_problem():
+    """bench.py generates each rank's rows from the stream position of its first row: the shards must be
+    exactly the rows of the single-GPU problem (inputs AND targets), or strong scaling compares different data."""
+    import numpy as np
+    from gp_amd import synth
+    from gp_amd.sharding import shard_range
+    seed, n, d = 20240604, 1001, 7
+    hyp = synth.eval_hyps(d)
+    X = synth.make_inputs(seed, n, d)
+    y = synth.make_targets(seed, X, hyp)
+    for world in (2, 3, 8):
+        for rank in range(world):
+            r0, r1 = shard_range(n, rank, world)
+            Xr = synth.make_inputs(seed, r1 - r0, d, start_point=r0)
+            yr = synth.make_targets(seed, Xr, hyp, start_point=r0)
+            assert np.array_equal(Xr, X[r0:r1]) and np.allclose(yr, y[r0:r1], rtol=0, atol=1e-12)

@@ -71,6 +71,9 @@ def test_sparse_random(gpx, model, seed):
     # widened only by the measured disagreement of two CPU evaluations on the same inputs (conditioning)
     tol_f = max(1e-9, 3 * abs(nll_n - nll_o) / max(1.0, abs(nll_o)))
     tol_g = max(1e-7, 3 * np.max(np.abs(g_n - g_o)) / max(1.0, np.max(np.abs(g_o))))
+    if tol_f > 1e-9 or tol_g > 1e-7:
+        print(f"\n[{model} seed={seed} n={n} m={m} d={d} jitter={jit:.1e}] bars widened to NLL {tol_f:.2e}, gradient {tol_g:.2e}")
+    assert tol_f <= 1e-7 and tol_g <= 1e-5, (tol_f, tol_g)  # a conditioning regression must not pass silently
     assert abs(nll - nll_o) <= tol_f * max(1.0, abs(nll_o)), (n, m, d, cov, jit)
     assert np.max(np.abs(g - g_o)) <= tol_g * max(1.0, np.max(np.abs(g_o))), (n, m, d, cov, jit)
     ctx.prepare(M, cov, hyp, jitter=jit)

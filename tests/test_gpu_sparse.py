@@ -58,6 +58,10 @@ def test_sparse_nll_grad_predict_vs_oracle(gpx, model, cov, n, d, m, jit):
     fn = np_gp.fitc_nll if model == "fitc" else np_gp.vfe_nll
     g_np = fn(cov, X, y, U, jit, hyp)[1]
     tol = max(1e-7, 3 * rel(g_np, g_o))
+    if tol > 1e-7:
+        print(f"\n[{model} cov={cov} n={n} m={m} jitter={jit:g}] gradient bar widened to {tol:.2e} "
+              f"(oracle-vs-NumPy {rel(g_np, g_o):.2e}, gpu-vs-NumPy {rel(g, g_np):.2e})")
+    assert tol <= 1e-5, tol                                # a conditioning regression must not pass silently
     assert rel(g, g_o) <= tol, (rel(g, g_o), rel(g_np, g_o), rel(g, g_np))
     assert ctx.nll_grad(M, cov, hyp, calc_grad=False, jitter=jit) == nll
     hyp2, jit2 = ctx.prepare(M, cov, hyp, jitter=jit)
