@@ -1,5 +1,6 @@
 // capi.hip — the high-level extern "C" entry points declared in include/gpx.h.
 #include "ctx.h"
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -15,6 +16,10 @@ int gpx_ctx_create(int device, gpx_ctx** out) {
     gpx_ctx* c = new (std::nothrow) gpx_ctx();
     if (!c) return GPX_ERR_HIP;
     c->dev = device;
+    {
+        const char* e = getenv("GPX_NO_MFMA_PAIRWISE");
+        c->mfma_pairwise = !(e && e[0] == '1');
+    }
     // non-blocking: no implicit ordering against the caller's NULL-stream work (e.g. a collective a
     // framework issues from the all-reduce hook); every entry point drains its own streams
     HIP_TRY(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
@@ -42,7 +47,8 @@ int gpx_ctx_destroy(gpx_ctx* c) {
                       &c->nalpha, &c->scal, &c->trace_ws, &c->Kxu, &c->V, &c->Bm, &c->Cm, &c->Kuu, &c->Lu,
                       &c->Am, &c->LA, &c->Winv_u, &c->Winv_A, &c->Kuu_inv, &c->A_inv, &c->Wuu,
                       &c->Wd_u, &c->Wd_A, &c->red, &c->pred_K, &c->pred_xs, &c->pred_xst, &c->pred_out,
-                      &c->pred_tmp, &c->pred_K2, &c->pred_g, &c->pLu, &c->pLA, &c->pWd_u, &c->pWd_A, &c->palpha, &c->pUt};
+                      &c->pred_tmp, &c->pred_K2, &c->pred_g, &c->pLu, &c->pLA, &c->pWd_u, &c->pWd_A, &c->palpha, &c->pUt,
+                      &c->Xa, &c->Ua, &c->UaT, &c->cen, &c->cpart, &c->spart, &c->cvec};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : c->vn) b.release();
     for (auto& b : c->vm) b.release();

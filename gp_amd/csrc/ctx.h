@@ -51,6 +51,9 @@ struct gpx_ctx {
     // sparse workspaces (sparse.hip)
     DevBuf Kxu, V, Bm, Cm, Kuu, Lu, Am, LA, Winv_u, Winv_A, Kuu_inv, A_inv, Wuu, Wd_u, Wd_A;
     DevBuf vn[8], vm[8], red;
+    // matrix-core pairwise path (pairwise_mfma.hip): centred, augmented operands and its partial sums
+    DevBuf Xa, Ua, UaT, cen, cpart, spart, cvec;
+    bool mfma_pairwise = true;   // GPX_NO_MFMA_PAIRWISE=1 keeps the vector-unit kernels (A/B runs, fallback tests)
     // all-reduce hook for row-sharded FITC/VFE
     gpx_allreduce_fn allreduce = nullptr;                 // host-synchronous flavour
     gpx_allreduce_stream_fn allreduce_stream = nullptr;   // stream-ordered flavour (preferred)

@@ -30,6 +30,24 @@ int gpx_pair_trace(hipStream_t st, TraceArgs g, int d, double* partial_ws, long 
 // HIP-event timing of cov_build (cls 0) / pair_trace (cls 1) launches that move >= min_bytes algorithmic bytes
 int gpx_pair_prof_begin(double min_bytes, int max_launches);
 int gpx_pair_prof_end(int cls, double* total_ms, double* total_bytes, long* launches);
+long gpx_pair_prof_open(hipStream_t st, int cls, double bytes);   // -1: not timed
+void gpx_pair_prof_close(hipStream_t st, long slot);
+
+// ---- pairwise_mfma.hip: the n x m kernel matrix and its gradient trace on the matrix cores ------------
+bool gpx_mfma_pair_supported(int d);   // d <= 62
+long gpx_mfma_ldxa(long n);            // row stride of Xa  [dk][ldxa]
+long gpx_mfma_ldua(long m);            // row stride of Ua  [dk][ldua]; UaT is [ldua][n2]
+int gpx_mfma_dk(int d);
+int gpx_mfma_n2(int d);
+int gpx_mfma_trace_grid(long n, int d);
+// centred, augmented operands from the scaled dimension-major inputs; Xa may be NULL (U side only)
+int gpx_mfma_prepare(hipStream_t st, const double* Xt, long ldx, long n, const double* Ut, long ldu, long m, int d,
+                     double* cen, double* Xa, double* Ua, double* UaT);
+int gpx_mfma_cov_build(hipStream_t st, const double* Xa, long n, const double* Ua, long m, int d, double sf2, double* out,
+                       long ldo);
+// weights from w (M1/c1, M2/c2, u/v); cpart: grid*ldua doubles, spart: grid*(n2+1), cvec: ldua
+int gpx_mfma_pair_trace(hipStream_t st, const double* Xa, long n, const double* Ua, const double* UaT, long m, int d, double sf2,
+                        const TraceArgs& w, double* cpart, double* spart, double* cvec, double* out);
 
 // ---- chol.hip -------------------------------------------------------------------------------
 // Blocked recursive lower Cholesky in place (lower triangle of A).  Wd (64 x roundup(n,64),

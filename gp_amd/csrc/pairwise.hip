@@ -416,6 +416,9 @@ int gpx_pair_trace(hipStream_t st, TraceArgs g, int d, double* partial_ws, long 
     return GPX_OK;
 }
 
+long gpx_pair_prof_open(hipStream_t st, int cls, double bytes) { return pp_open(st, cls, bytes); }
+void gpx_pair_prof_close(hipStream_t st, long slot) { pp_close(st, slot); }
+
 int gpx_pair_prof_begin(double min_bytes, int max_launches) {
     std::lock_guard<std::mutex> lk(p_prof.mu);
     if (p_prof.ev.size() < (size_t)max_launches * 2) {

@@ -1,0 +1,493 @@
+// pairwise_mfma.hip — the n x m kernel matrix Kxu and the fused gradient trace over it ON THE MATRIX CORES
+// (v_mfma_f64_16x16x4_f64, gfx950), for the sparse models (FITC.cpp:204, 269-308; VFE.cpp:168, 213-237;
+// Cov/CovSEard.cpp:7-22).
+//
+//  * squared distances by the norm expansion the reference keeps as a commented variant (util.cpp:67-69):
+//      r2_ab = |x_a|^2 + |u_b|^2 - 2 x_a.u_b  =  sum_c Xa[c][a] * Ua[c][b]
+//    with AUGMENTED operands  Xa = [x~ ; |x~|^2 ; 1],  Ua = [-2 u~ ; 1 ; |u~|^2]  (x~, u~ = lengthscale-scaled
+//    inputs, centred on the mean inducing point: distances are translation invariant and the centring keeps
+//    |x~|^2 of the order of r2, so the cancellation costs a few ulps of r2, not of |x|^2).  One contraction of
+//    depth dk = roundup(d + 2, 4) per pair, no vector-unit work for r2 at all; r2 is clamped at 0.
+//  * gradient sums: with Q = W o K per tile (one exp per pair stays on the vector unit)
+//      sum_ab Q_ab (x~_ia - u~_ib)^2 = sum_a x~_ia^2 (Q 1)_a + sum_a x~_ia (Q [-2 U~])_ai + sum_b u~_ib^2 (Q^T 1)_b
+//    The MFMA accumulator layout of the r2 tile (lane holds [b = 4r + lane/16][a = lane%16]) IS the operand
+//    layout of a second MFMA that contracts over b: Q goes from the first product into the second without
+//    leaving its registers, and [Q(-2U~) | Q1] (d + 1 columns) accumulates over all inducing points of a row
+//    block.  The column sums Q^T 1 are a 16-lane reduction per tile.  3 d vector operations per pair become
+//    2 (dk + 16 ceil((d+1)/16)) matrix flops per pair.
+//
+// Workgroup = 4 waves = 128 training rows (32 per wave: two interleaved 16-row MFMA tiles, so that a lane's two
+// rows are adjacent in memory and every weight load is 16 B); inducing points go through LDS 64 at a time in two
+// images (row-major for the first product, transposed for the second), both conflict-free for their fragment
+// reads.  k(X,X) of the exact path and Kuu keep the direct-difference kernels of pairwise.hip (exact sf2
+// diagonal, as util.cpp:64-75 computes it).
+#include "gpx_internal.h"
+#include "kernels.h"
+
+namespace {
+
+struct MfmaPairArgs {
+    const double* Xa; long ldxa; long n;    // [dk][ldxa], ldxa = roundup(n, 128), zero beyond n
+    const double* Ua; long ldua; long m;    // [dk][ldua], ldua = roundup(m, 64), zero beyond m
+    const double* UaT;                      // [ldua][N2]: rows 0..d of Ua, transposed, zero padded
+    int d;
+    double sf2;
+    // cov build
+    double* out; long ldo;
+    // trace: w_ab = c1_a * M1_ab + c2_a * M2_ab + u_a * v_b
+    const double* M1; long ldm1; const double* c1;
+    const double* M2; long ldm2; const double* c2;
+    const double* u; const double* v;
+    double* cpart;   // [gridDim][ldua] column sums of Q per workgroup (zero on entry)
+    double* spart;   // [gridDim][N2 + 1]
+    int nblk;        // row blocks of the trace kernel (128 or 64 rows)
+};
+
+template <int KK>
+struct Cfg {
+    static constexpr int DK = 4 * KK;                      // depth of the r2 contraction (>= d + 2)
+    static constexpr int JT = (4 * KK - 1 + 15) / 16;      // 16-column tiles of [Q(-2U) | Q1] (>= d + 1 columns)
+    static constexpr int N2 = 16 * JT;
+    // inducing points per LDS tile: 64, or 32 for the deep contractions, whose two images of a 64-point tile
+    // (79 KB) would leave room for ONE workgroup per CU only
+    static constexpr int TB = KK <= 8 ? 64 : 32;
+    static constexpr int S1 = TB + 16;                     // row stride of image 1 [DK][TB]: = 128 B mod 256 B
+    static constexpr int S2 = (N2 % 32 == 16) ? N2 : N2 + 16;  // row stride of image 2 [TB][N2]: = 128 B mod 256 B
+};
+
+__device__ __forceinline__ v4d mfma(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+// stage one tile of 64 inducing points: image 1 sU[c][b] (first product: A operand rows = b, k = c),
+// image 2 sUT[b][c] (second product: B operand k = b, columns = c)
+template <int KK, bool WITH_T>
+__device__ __forceinline__ void stage_u(const MfmaPairArgs& g, long b0, double* __restrict__ sU, double* __restrict__ sUT) {
+    using C = Cfg<KK>;
+    for (int idx = threadIdx.x; idx < C::DK * C::TB; idx += 256) {
+        const int c = idx / C::TB, b = idx % C::TB;
+        sU[c * C::S1 + b] = g.Ua[(long)c * g.ldua + b0 + b];
+    }
+    if (WITH_T) {
+        for (int idx = threadIdx.x; idx < C::TB * C::N2; idx += 256) {
+            const int b = idx / C::N2, c = idx % C::N2;
+            sUT[b * C::S2 + c] = g.UaT[(b0 + b) * C::N2 + c];
+        }
+    }
+}
+
+// K_ab = sf2 exp(-r2/2) for one row block of 128 x all inducing points
+template <int KK>
+__global__ __launch_bounds__(256, 2) void cov_mfma_kernel(const MfmaPairArgs g) {
+    using C = Cfg<KK>;
+    __shared__ __attribute__((aligned(16))) double sU[C::DK * C::S1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const long a0 = (long)blockIdx.x * 128 + 32 * wv + 2 * l15;   // this lane's two rows: a0, a0 + 1
+    double xf[2][KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+        const v2d x = *reinterpret_cast<const v2d*>(g.Xa + (long)(4 * kk + l4) * g.ldxa + a0);
+        xf[0][kk] = x.x;
+        xf[1][kk] = x.y;
+    }
+    const bool rows_in = (long)blockIdx.x * 128 + 128 <= g.n;
+    const bool vec = ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (g.ldo % 2 == 0);
+    for (long b0 = 0; b0 < g.m; b0 += C::TB) {
+        __syncthreads();
+        stage_u<KK, false>(g, b0, sU, nullptr);
+        __syncthreads();
+        const bool full = rows_in && vec && b0 + C::TB <= g.m;
+#pragma unroll
+        for (int bt = 0; bt < C::TB / 16; ++bt) {
+            v4d D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const double ua = sU[(4 * kk + l4) * C::S1 + 16 * bt + l15];
+                D0 = mfma(ua, xf[0][kk], D0);
+                D1 = mfma(ua, xf[1][kk], D1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long b = b0 + 16 * bt + 4 * r + l4;
+                const double k0 = g.sf2 * exp(-0.5 * fmax(D0[r], 0.0));
+                const double k1 = g.sf2 * exp(-0.5 * fmax(D1[r], 0.0));
+                double* o = g.out + a0 + b * g.ldo;
+                if (full) {
+                    *reinterpret_cast<v2d*>(o) = (v2d){k0, k1};
+                } else if (b < g.m) {
+                    if (a0 < g.n) o[0] = k0;
+                    if (a0 + 1 < g.n) o[1] = k1;
+                }
+            }
+        }
+    }
+}
+
+// the fused gradient trace: per workgroup partial sums of
+//   S_c = sum_a x~_ca (x~_ca (Q1)_a + (Q[-2U~])_ac)   c < d,      S_K = sum_ab Q_ab,      colsum_b = sum_a Q_ab
+// NS = 16-row MFMA tiles per wave (rows per workgroup = 64 NS): 2 while the X fragments and the [Q(-2U) | Q1]
+// accumulators of two tiles fit the register file beside the exp, 1 for the deep contractions (d > 30)
+template <int KK, bool HAS_M2, int NS>
+__global__ __launch_bounds__(256, 2) void trace_mfma_kernel(const MfmaPairArgs g) {
+    using C = Cfg<KK>;
+    constexpr int JT = C::JT;
+    constexpr int RB = 64 * NS;   // rows per workgroup
+    __shared__ __attribute__((aligned(16))) double sU[C::DK * C::S1];
+    constexpr int TB = C::TB;
+    __shared__ __attribute__((aligned(16))) double sUT[TB * C::S2];
+    __shared__ double sv[TB];
+    __shared__ double csum[4][TB];
+    __shared__ double red[4][C::N2 + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int d = g.d;
+    double accS[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) accS[jt] = 0.0;
+    double accK = 0.0;
+    double* cp = g.cpart + (long)blockIdx.x * g.ldua;
+    const bool vec = NS == 1 || (((reinterpret_cast<uintptr_t>(g.M1) & 15) == 0) && (g.ldm1 % 2 == 0) &&
+                                 (!HAS_M2 || (((reinterpret_cast<uintptr_t>(g.M2) & 15) == 0) && (g.ldm2 % 2 == 0))));
+
+    for (int blk = blockIdx.x; blk < g.nblk; blk += gridDim.x) {
+        const long a0 = (long)blk * RB + 16 * NS * wv + NS * l15;   // this lane's NS adjacent rows in the r2 tiles
+        double xf[NS][KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const double* px = g.Xa + (long)(4 * kk + l4) * g.ldxa + a0;
+            if (NS == 2) {
+                const v2d x = *reinterpret_cast<const v2d*>(px);
+                xf[0][kk] = x.x;
+                xf[NS - 1][kk] = x.y;
+            } else {
+                xf[0][kk] = px[0];
+            }
+        }
+        double c1a[NS], c2a[NS], ua[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const bool in = a0 + s < g.n;
+            c1a[s] = (in && g.c1) ? g.c1[a0 + s] : 1.0;
+            c2a[s] = (HAS_M2 && in && g.c2) ? g.c2[a0 + s] : 1.0;
+            ua[s] = (in && g.u) ? g.u[a0 + s] : 0.0;
+        }
+        v4d acc2[NS][JT];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) acc2[s][jt] = (v4d){0, 0, 0, 0};
+        const bool rows_in = (long)blk * RB + RB <= g.n;
+
+        for (long b0 = 0; b0 < g.m; b0 += TB) {
+            const bool full = rows_in && vec && b0 + TB <= g.m;
+            // single weight matrix, one row per lane: all 16 weights of the tile are requested BEFORE the
+            // inducing points are staged, so that the HBM latency hides behind the staging and the first products
+            constexpr bool PF = !HAS_M2 && NS == 1;
+            double wpf[PF ? TB / 4 : 1];
+            if (PF) {
+#pragma unroll
+                for (int i = 0; i < TB / 4; ++i) {
+                    const long b = b0 + 4 * i + l4;   // i = 4 bt + r
+                    wpf[i] = (full || (b < g.m && a0 < g.n)) ? g.M1[a0 + b * g.ldm1] : 0.0;
+                }
+            }
+            __syncthreads();   // the previous tile's fragments are consumed, its column sums are in csum
+            if (b0 > 0 && threadIdx.x < TB)
+                cp[b0 - TB + threadIdx.x] += (csum[0][threadIdx.x] + csum[1][threadIdx.x]) + (csum[2][threadIdx.x] + csum[3][threadIdx.x]);
+            stage_u<KK, true>(g, b0, sU, sUT);
+            if (threadIdx.x < TB) sv[threadIdx.x] = (g.v && b0 + threadIdx.x < g.m) ? g.v[b0 + threadIdx.x] : 0.0;
+            __syncthreads();
+#pragma unroll
+            for (int bt = 0; bt < TB / 16; ++bt) {
+                // weights of this 16-column group first: their latency hides behind the r2 product
+                double w1[4][NS], w2[4][NS];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (PF) {
+                        w1[r][0] = wpf[4 * bt + r];
+                        continue;
+                    }
+                    const long b = b0 + 16 * bt + 4 * r + l4;
+                    const double* p1 = g.M1 + a0 + b * g.ldm1;
+                    const double* p2 = HAS_M2 ? g.M2 + a0 + b * g.ldm2 : nullptr;
+                    if (full) {
+                        if (NS == 2) {
+                            const v2d t = *reinterpret_cast<const v2d*>(p1);
+                            w1[r][0] = t.x;
+                            w1[r][NS - 1] = t.y;
+                            if (HAS_M2) {
+                                const v2d t2 = *reinterpret_cast<const v2d*>(p2);
+                                w2[r][0] = t2.x;
+                                w2[r][NS - 1] = t2.y;
+                            }
+                        } else {
+                            w1[r][0] = p1[0];
+                            if (HAS_M2) w2[r][0] = p2[0];
+                        }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            const bool in = b < g.m && a0 + s < g.n;
+                            w1[r][s] = in ? p1[s] : 0.0;
+                            if (HAS_M2) w2[r][s] = in ? p2[s] : 0.0;
+                        }
+                    }
+                }
+                v4d D[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) D[s] = (v4d){0, 0, 0, 0};
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    const double uf = sU[(4 * kk + l4) * C::S1 + 16 * bt + l15];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) D[s] = mfma(uf, xf[s][kk], D[s]);
+                }
+                double q[NS][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int bl = 16 * bt + 4 * r + l4;
+                    const double vb = sv[bl];
+                    // beyond n / m the operands are zero, so K = sf2 there: the weights must vanish instead
+                    const bool bin = b0 + bl < g.m;
+                    double cs = 0.0;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        double w = c1a[s] * w1[r][s];
+                        if (HAS_M2) w = fma(c2a[s], w2[r][s], w);
+                        w = fma(ua[s], vb, w);
+                        if (!bin) w = 0.0;
+                        q[s][r] = w * (g.sf2 * exp(-0.5 * fmax(D[s][r], 0.0)));
+                        cs += q[s][r];
+                    }
+                    // column sum over this wave's rows
+                    cs += __shfl_xor(cs, 1, 64);
+                    cs += __shfl_xor(cs, 2, 64);
+                    cs += __shfl_xor(cs, 4, 64);
+                    cs += __shfl_xor(cs, 8, 64);
+                    if (l15 == 0) csum[wv][bl] = cs;
+                }
+                // second product: [Q(-2U~) | Q1] += Q * UaT, contraction over the 16 inducing points of this group
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        const double ub = sUT[(16 * bt + 4 * r + l4) * C::S2 + 16 * jt + l15];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) acc2[s][jt] = mfma(q[s][r], ub, acc2[s][jt]);
+                    }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < TB) {
+            const long bl = (g.m - 1) / TB * TB;
+            cp[bl + threadIdx.x] += (csum[0][threadIdx.x] + csum[1][threadIdx.x]) + (csum[2][threadIdx.x] + csum[3][threadIdx.x]);
+        }
+        // end of the row block: acc2[s][jt][r] = row a = base + NS (l4 + 4 r) + s, column c = 16 jt + l15
+        const int jtd = d >> 4, ld = d & 15;   // column d holds (Q 1)_a
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double q1a = 0.0;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+                    if (jt == jtd) q1a = acc2[s][jt][r];
+                q1a = __shfl(q1a, (lane & 48) | ld, 64);
+                const long a = (long)blk * RB + 16 * NS * wv + NS * (l4 + 4 * r) + s;
+                if (l15 == 0) accK += q1a;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    const int c = 16 * jt + l15;
+                    if (c < d) {
+                        const double x = g.Xa[(long)c * g.ldxa + a];   // zero beyond n
+                        accS[jt] = fma(x, fma(x, q1a, acc2[s][jt][r]), accS[jt]);
+                    }
+                }
+            }
+    }
+    // workgroup partials: column c = 16 jt + l15 summed over l4 and the four waves
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        double s = accS[jt];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (l4 == 0) red[wv][16 * jt + l15] = s;
+    }
+    {
+        double s = accK;
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (lane == 0) red[wv][C::N2] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x <= C::N2)
+        g.spart[(long)blockIdx.x * (C::N2 + 1) + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---- operand preparation ----------------------------------------------------------------------------
+// cen[i] = mean over the m inducing points of the scaled coordinate i
+__global__ void centre_kernel(const double* __restrict__ Ut, long ldu, long m, double* __restrict__ cen) {
+    __shared__ double red[256];
+    const int i = blockIdx.x;
+    double s = 0.0;
+    for (long b = threadIdx.x; b < m; b += 256) s += Ut[(long)i * ldu + b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cen[i] = red[0] / (double)m;
+}
+
+// side 0: Xa = [x~ ; |x~|^2 ; 1 ; 0..]      side 1: Ua = [-2 u~ ; 1 ; |u~|^2 ; 0..] and UaT = rows 0..d transposed
+__global__ void augment_kernel(const double* __restrict__ Xt, long ldx, long cnt, int d, int dk, const double* __restrict__ cen,
+                               int side, double* __restrict__ A, long lda, double* __restrict__ AT, int n2) {
+    const long a = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= lda) return;
+    const bool in = a < cnt;
+    double nrm = 0.0;
+    for (int i = 0; i < d; ++i) {
+        const double v = in ? Xt[(long)i * ldx + a] - cen[i] : 0.0;
+        nrm = fma(v, v, nrm);
+        const double o = side ? -2.0 * v : v;
+        A[(long)i * lda + a] = o;
+        if (AT) AT[a * n2 + i] = o;
+    }
+    const double one = in ? 1.0 : 0.0;
+    A[(long)d * lda + a] = side ? one : nrm;
+    A[(long)(d + 1) * lda + a] = side ? nrm : one;
+    for (int i = d + 2; i < dk; ++i) A[(long)i * lda + a] = 0.0;
+    if (AT) {
+        AT[a * n2 + d] = one;
+        for (int i = d + 1; i < n2; ++i) AT[a * n2 + i] = 0.0;
+    }
+}
+
+__global__ void colsum_finish_kernel(const double* __restrict__ cpart, int nwg, long ldua, double* __restrict__ cvec) {
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= ldua) return;
+    double s = 0.0;
+    for (int w = 0; w < nwg; ++w) s += cpart[(long)w * ldua + b];
+    cvec[b] = s;
+}
+
+// out[i] = sum_wg spart[wg][i] + sum_b u~_ib^2 colsum_b  (i < d);  out[d] = sum_ab Q_ab;  out[d+1] = 0
+__global__ void trace_mfma_finish_kernel(const double* __restrict__ spart, int nwg, int n2, const double* __restrict__ Ua,
+                                         long ldua, long m, const double* __restrict__ cvec, int d, double* __restrict__ out) {
+    __shared__ double red[256];
+    const int i = blockIdx.x;
+    double s = 0.0;
+    const int col = i < d ? i : n2;
+    for (int w = threadIdx.x; w < nwg; w += 256) s += spart[(long)w * (n2 + 1) + col];
+    if (i < d)
+        for (long b = threadIdx.x; b < m; b += 256) {
+            const double t = Ua[(long)i * ldua + b];   // -2 u~
+            s = fma(0.25 * t * t, cvec[b], s);
+        }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[i] = red[0];
+        if (i == d) out[d + 1] = 0.0;
+    }
+}
+
+#define GPX_KK_CASE(KERNEL, K, grid, st, args) \
+    case K: hipLaunchKernelGGL((KERNEL(K)), dim3(grid), dim3(256), 0, st, args); break;
+#define GPX_KK_SWITCH(KERNEL, kk, grid, st, args)                                                         \
+    switch (kk) {                                                                                          \
+        GPX_KK_CASE(KERNEL, 1, grid, st, args) GPX_KK_CASE(KERNEL, 2, grid, st, args)                      \
+        GPX_KK_CASE(KERNEL, 3, grid, st, args) GPX_KK_CASE(KERNEL, 4, grid, st, args)                      \
+        GPX_KK_CASE(KERNEL, 5, grid, st, args) GPX_KK_CASE(KERNEL, 6, grid, st, args)                      \
+        GPX_KK_CASE(KERNEL, 7, grid, st, args) GPX_KK_CASE(KERNEL, 8, grid, st, args)                      \
+        GPX_KK_CASE(KERNEL, 9, grid, st, args) GPX_KK_CASE(KERNEL, 10, grid, st, args)                     \
+        GPX_KK_CASE(KERNEL, 11, grid, st, args) GPX_KK_CASE(KERNEL, 12, grid, st, args)                    \
+        GPX_KK_CASE(KERNEL, 13, grid, st, args) GPX_KK_CASE(KERNEL, 14, grid, st, args)                    \
+        GPX_KK_CASE(KERNEL, 15, grid, st, args)                                                            \
+        default: hipLaunchKernelGGL((KERNEL(16)), dim3(grid), dim3(256), 0, st, args); break;              \
+    }
+#define GPX_COV_K(K) cov_mfma_kernel<K>
+#define GPX_TRACE_NS(K) ((K) <= 8 ? 2 : 1)
+#define GPX_TRACE_K1(K) trace_mfma_kernel<K, false, GPX_TRACE_NS(K)>
+#define GPX_TRACE_K2(K) trace_mfma_kernel<K, true, GPX_TRACE_NS(K)>
+
+inline int kk_of(int d) { return (d + 2 + 3) / 4; }
+inline int n2_of(int d) { return 16 * ((4 * kk_of(d) - 1 + 15) / 16); }
+
+}  // namespace
+
+bool gpx_mfma_pair_supported(int d) { return d >= 1 && kk_of(d) <= 16; }
+long gpx_mfma_ldxa(long n) { return (n + 127) / 128 * 128; }
+long gpx_mfma_ldua(long m) { return (m + 63) / 64 * 64; }
+int gpx_mfma_dk(int d) { return 4 * kk_of(d); }
+int gpx_mfma_n2(int d) { return n2_of(d); }
+static inline int trace_rows(int d) { return kk_of(d) <= 8 ? 128 : 64; }   // rows per workgroup of the trace kernel
+int gpx_mfma_trace_grid(long n, int d) {
+    const long nblk = (n + trace_rows(d) - 1) / trace_rows(d);
+    return (int)(nblk < 512 ? nblk : 512);   // 2 workgroups per CU x 256 CUs; a fixed function of (n, d): deterministic sums
+}
+
+int gpx_mfma_prepare(hipStream_t st, const double* Xt, long ldx, long n, const double* Ut, long ldu, long m, int d,
+                     double* cen, double* Xa, double* Ua, double* UaT) {
+    if (!gpx_mfma_pair_supported(d)) return GPX_ERR_UNSUPPORTED;
+    const int dk = gpx_mfma_dk(d), n2 = gpx_mfma_n2(d);
+    const long ldxa = gpx_mfma_ldxa(n), ldua = gpx_mfma_ldua(m);
+    hipLaunchKernelGGL(centre_kernel, dim3(d), dim3(256), 0, st, Ut, ldu, m, cen);
+    hipLaunchKernelGGL(augment_kernel, dim3((unsigned)((ldua + 255) / 256)), dim3(256), 0, st, Ut, ldu, m, d, dk, cen, 1, Ua, ldua,
+                       UaT, n2);
+    if (Xa)
+        hipLaunchKernelGGL(augment_kernel, dim3((unsigned)((ldxa + 255) / 256)), dim3(256), 0, st, Xt, ldx, n, d, dk, cen, 0, Xa,
+                           ldxa, (double*)nullptr, n2);
+    HIP_TRY(hipGetLastError());
+    return GPX_OK;
+}
+
+int gpx_mfma_cov_build(hipStream_t st, const double* Xa, long n, const double* Ua, long m, int d, double sf2, double* out,
+                       long ldo) {
+    if (n <= 0 || m <= 0) return GPX_OK;
+    MfmaPairArgs g = {};
+    g.Xa = Xa; g.ldxa = gpx_mfma_ldxa(n); g.n = n;
+    g.Ua = Ua; g.ldua = gpx_mfma_ldua(m); g.m = m;
+    g.d = d; g.sf2 = sf2; g.out = out; g.ldo = ldo;
+    const long nblk = (n + 127) / 128;
+    if (nblk > 0x7fffffffL) return GPX_ERR_ARG;
+    const long slot = gpx_pair_prof_open(st, 0, 8.0 * (double)n * (double)m);
+    GPX_KK_SWITCH(GPX_COV_K, kk_of(d), (unsigned)nblk, st, g);
+    gpx_pair_prof_close(st, slot);
+    HIP_TRY(hipGetLastError());
+    return GPX_OK;
+}
+
+// out[0..d-1] = S_i, out[d] = sum W K, out[d+1] = 0.  cpart: grid * ldua doubles, spart: grid * (N2 + 1), cvec: ldua.
+int gpx_mfma_pair_trace(hipStream_t st, const double* Xa, long n, const double* Ua, const double* UaT, long m, int d, double sf2,
+                        const TraceArgs& w, double* cpart, double* spart, double* cvec, double* out) {
+    if (n <= 0 || m <= 0) return GPX_ERR_ARG;
+    MfmaPairArgs g = {};
+    g.Xa = Xa; g.ldxa = gpx_mfma_ldxa(n); g.n = n;
+    g.Ua = Ua; g.ldua = gpx_mfma_ldua(m); g.m = m;
+    g.UaT = UaT;
+    g.d = d; g.sf2 = sf2;
+    g.M1 = w.M1; g.ldm1 = w.ldm1; g.c1 = w.c1;
+    g.M2 = w.M2; g.ldm2 = w.ldm2; g.c2 = w.c2;
+    g.u = w.u; g.v = w.v;
+    g.cpart = cpart; g.spart = spart;
+    const long nblk = (n + trace_rows(d) - 1) / trace_rows(d);
+    if (nblk > 0x7fffffffL) return GPX_ERR_ARG;
+    g.nblk = (int)nblk;
+    const int grid = gpx_mfma_trace_grid(n, d), n2 = gpx_mfma_n2(d);
+    HIP_TRY(hipMemsetAsync(cpart, 0, (size_t)grid * g.ldua * sizeof(double), st));
+    const long slot = gpx_pair_prof_open(st, 1, 8.0 * (double)n * (double)m * (w.M2 ? 2.0 : 1.0));
+    if (w.M2) {
+        GPX_KK_SWITCH(GPX_TRACE_K2, kk_of(d), (unsigned)grid, st, g);
+    } else {
+        GPX_KK_SWITCH(GPX_TRACE_K1, kk_of(d), (unsigned)grid, st, g);
+    }
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((g.ldua + 255) / 256)), dim3(256), 0, st, cpart, grid, g.ldua, cvec);
+    hipLaunchKernelGGL(trace_mfma_finish_kernel, dim3(d + 1), dim3(256), 0, st, spart, grid, n2, Ua, g.ldua, m, cvec, d, out);
+    gpx_pair_prof_close(st, slot);
+    HIP_TRY(hipGetLastError());
+    return GPX_OK;
+}

@@ -216,10 +216,19 @@ struct Sparse {
     int d, model, cov;
     HypView h;
 
+    bool mfma() const { return c->mfma_pairwise && gpx_mfma_pair_supported(d); }
     int alloc(bool grad) {
         int rc;
         ldn = gpx_ld(n);
         ldm = gpx_ld(m);
+        if (mfma()) {
+            const long ldxa = gpx_mfma_ldxa(n), ldua = gpx_mfma_ldua(m);
+            const int dk = gpx_mfma_dk(d), n2 = gpx_mfma_n2(d), grid = gpx_mfma_trace_grid(n, d);
+            if ((rc = c->Xa.ensure(dk * ldxa)) || (rc = c->Ua.ensure(dk * ldua)) || (rc = c->UaT.ensure(ldua * n2)) ||
+                (rc = c->cen.ensure(GPX_MAX_DIM)) || (rc = c->cvec.ensure(ldua)))
+                return rc;
+            if (grad && ((rc = c->cpart.ensure((long)grid * ldua)) || (rc = c->spart.ensure((long)grid * (n2 + 1))))) return rc;
+        }
         const long nm = ldn * m, mm = ldm * m;
         if ((rc = c->Kxu.ensure(nm))) return rc;
         if (model == GPX_MODEL_FITC) {
@@ -277,6 +286,23 @@ struct Sparse {
         hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, Inv, ldm);
         return GPX_OK;
     }
+    // Kxu = k(X, U): on the matrix cores (norm expansion of centred inputs) where the dimension allows it,
+    // else by direct differences on the vector units
+    int build_kxu() {
+        int rc;
+        if (mfma()) {
+            if ((rc = gpx_mfma_prepare(st, c->Xt.p, c->ldx, n, c->Ut.p, c->ldu, m, d, c->cen.p, c->Xa.p, c->Ua.p, c->UaT.p)))
+                return rc;
+            return gpx_mfma_cov_build(st, c->Xa.p, n, c->Ua.p, m, d, h.sf2, c->Kxu.p, ldn);
+        }
+        return gpx_cov_build(st, c->Xt.p, c->ldx, n, c->Ut.p, c->ldu, m, c->dpad, h.sf2, c->Kxu.p, ldn, 0, 0.0);
+    }
+    // sum_ab W_ab dKxu_ab/dtheta for every kernel hyper in one pass (weights in ta)
+    int trace_xu(const TraceArgs& ta, double* out) {
+        if (mfma())
+            return gpx_mfma_pair_trace(st, c->Xa.p, n, c->Ua.p, c->UaT.p, m, d, h.sf2, ta, c->cpart.p, c->spart.p, c->cvec.p, out);
+        return gpx_pair_trace(st, ta, d, c->trace_ws.p, c->trace_ws.cap, out);
+    }
     // inputs, Kuu (+jitter on its diagonal) factored into Lu, Kxu
     // overlap: the Lu factor+inverse chain (one workgroup wide for most of its length) runs on the
     // side stream while the main stream builds Kxu.
@@ -295,8 +321,7 @@ struct Sparse {
                 sf = c->st2;
                 HIP_TRY(hipEventRecord(c->ev[0], st));
                 HIP_TRY(hipStreamWaitEvent(sf, c->ev[0], 0));
-                if ((rc = gpx_cov_build(st, c->Xt.p, c->ldx, n, c->Ut.p, c->ldu, m, c->dpad, h.sf2, c->Kxu.p, ldn, 0, 0.0)))
-                    return rc;
+                if ((rc = build_kxu())) return rc;
                 if ((rc = gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p))) return rc;
             }
             HIP_TRY(hipMemsetAsync(c->Winv_u.p, 0, (size_t)ldm * m * sizeof(double), sf));
@@ -309,8 +334,7 @@ struct Sparse {
         } else if ((rc = gpx_potrf(st, m, c->Lu.p, ldm, c->Wd_u.p, c->info))) {
             return rc;
         }
-        if ((rc = gpx_cov_build(st, c->Xt.p, c->ldx, n, c->Ut.p, c->ldu, m, c->dpad, h.sf2, c->Kxu.p, ldn, 0, 0.0)))
-            return rc;
+        if ((rc = build_kxu())) return rc;
         return gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p);
     }
 };
@@ -450,7 +474,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         ta.M1 = Cm; ta.ldm1 = ldn; ta.c1 = g;
         ta.M2 = c->Bm.p; ta.ldm2 = ldn; ta.c2 = c2coef;
         ta.u = ucoef;
-        if ((rc = gpx_pair_trace(st, ta, d, c->trace_ws.p, c->trace_ws.cap, redT))) return rc;
+        if ((rc = s.trace_xu(ta, redT))) return rc;
         // B^T diag(w) B: w (signed) is the K-dimension scale of the lower-tile split-K product
         if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Bm.p, ldn, c->Bm.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
                                   wv)))
@@ -471,7 +495,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         s.finish_partials(n, redT + GPX_MAX_DIM + 8, 2);  // sum alpha^2, sum alpha
         ta.M1 = c->Cm.p; ta.ldm1 = ldn;
         ta.u = nalpha;
-        if ((rc = gpx_pair_trace(st, ta, d, c->trace_ws.p, c->trace_ws.cap, redT))) return rc;
+        if ((rc = s.trace_xu(ta, redT))) return rc;
         // tr(A^-1 S) and G = Kuu^-1 S Kuu^-1 use the reduced S (still in red[0..m*m), symmetrised)
         hipLaunchKernelGGL(mm_inner_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, c->A_inv.p, ldm, red, m, s.part());
         s.finish_partials(m * m, c->scal.p + S_TRAS, 1);
