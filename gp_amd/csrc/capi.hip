@@ -225,4 +225,92 @@ int gpx_chol_solve(int64_t n, const double* A, int* spd, double* logdet, double*
     return done(GPX_OK);
 }
 
+// ---- MatrixSolverLLT with the factor kept on the device between decomp() and solve() / inverse() ----
+struct gpx_chol {
+    int dev = 0;
+    long n = 0, ld = 0;
+    DevBuf L, Wd;
+    bool spd = false;
+};
+
+int gpx_chol_factor(int64_t n, const double* A, gpx_chol** out, int* spd, double* logdet) {
+    if (!A || !out || !spd || n <= 0) return GPX_ERR_ARG;
+    *out = nullptr;
+    gpx_chol* f = new (std::nothrow) gpx_chol();
+    if (!f) return GPX_ERR_HIP;
+    auto fail = [&](int r) {
+        f->L.release(); f->Wd.release();
+        delete f;
+        return r;
+    };
+    if (hipGetDevice(&f->dev) != hipSuccess) return fail(GPX_ERR_HIP);
+    f->n = n;
+    f->ld = gpx_ld(n);
+    int rc = f->L.ensure(f->ld * n);
+    if (!rc) rc = f->Wd.ensure(64L * ((n + 63) / 64 * 64) + 16);
+    if (rc) return fail(rc);
+    int* info = reinterpret_cast<int*>(f->Wd.p + 64L * ((n + 63) / 64 * 64));  // device flag + log-det slot behind Wd
+    double* sc = f->Wd.p + 64L * ((n + 63) / 64 * 64) + 8;
+    if (hipMemcpy2D(f->L.p, f->ld * 8, A, n * 8, n * 8, n, hipMemcpyHostToDevice) != hipSuccess) return fail(GPX_ERR_HIP);
+    if (hipMemset(info, 0, 8) != hipSuccess) return fail(GPX_ERR_HIP);
+    if ((rc = gpx_potrf(0, n, f->L.p, f->ld, f->Wd.p, info))) return fail(rc);
+    int hinfo = 0;
+    if (hipMemcpy(&hinfo, info, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(GPX_ERR_HIP);
+    f->spd = hinfo == 0;
+    *spd = f->spd ? 1 : 0;
+    if (f->spd && logdet) {
+        if ((rc = gpx_logdiag_sum(0, n, f->L.p, f->ld, sc))) return fail(rc);
+        double v;
+        if (hipMemcpy(&v, sc, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(GPX_ERR_HIP);
+        *logdet = 2 * v;
+    }
+    *out = f;
+    return GPX_OK;
+}
+
+int gpx_chol_solve_factored(const gpx_chol* f, double* B, int64_t nrhs) {
+    if (!f || !B || nrhs <= 0) return GPX_ERR_ARG;
+    if (!f->spd) return GPX_ERR_STATE;
+    HIP_TRY(hipSetDevice(f->dev));
+    const long n = f->n, ld = f->ld;
+    DevBuf Bd;
+    int rc = Bd.ensure(ld * nrhs);
+    if (rc) return rc;
+    auto done = [&](int r) { Bd.release(); return r; };
+    if (hipMemcpy2D(Bd.p, ld * 8, B, n * 8, n * 8, nrhs, hipMemcpyHostToDevice) != hipSuccess) return done(GPX_ERR_HIP);
+    if ((rc = gpx_trsm_left(0, n, nrhs, f->L.p, ld, f->Wd.p, Bd.p, ld, 0))) return done(rc);
+    if ((rc = gpx_trsm_left(0, n, nrhs, f->L.p, ld, f->Wd.p, Bd.p, ld, 1))) return done(rc);
+    if (hipMemcpy2D(B, n * 8, Bd.p, ld * 8, n * 8, nrhs, hipMemcpyDeviceToHost) != hipSuccess) return done(GPX_ERR_HIP);
+    return done(GPX_OK);
+}
+
+int gpx_chol_inverse_factored(const gpx_chol* f, double* Inv) {
+    if (!f || !Inv) return GPX_ERR_ARG;
+    if (!f->spd) return GPX_ERR_STATE;
+    HIP_TRY(hipSetDevice(f->dev));
+    const long n = f->n, ld = f->ld;
+    DevBuf W, T, O;
+    int rc = W.ensure(ld * n);
+    if (!rc) rc = T.ensure(gpx_trtri_scratch(n));
+    if (!rc) rc = O.ensure(ld * n);
+    auto done = [&](int r) { W.release(); T.release(); O.release(); return r; };
+    if (rc) return done(rc);
+    if (hipMemset(W.p, 0, (size_t)ld * n * 8) != hipSuccess) return done(GPX_ERR_HIP);
+    if ((rc = gpx_trtri(0, n, f->L.p, ld, f->Wd.p, W.p, ld, T.p))) return done(rc);
+    if ((rc = gpx_lauum(0, n, W.p, ld, O.p, ld))) return done(rc);
+    if (hipMemcpy2D(Inv, n * 8, O.p, ld * 8, n * 8, n, hipMemcpyDeviceToHost) != hipSuccess) return done(GPX_ERR_HIP);
+    for (int64_t j = 0; j < n; ++j)   // the device keeps only the lower tiles
+        for (int64_t i = j + 1; i < n; ++i) Inv[j + i * n] = Inv[i + j * n];
+    return done(GPX_OK);
+}
+
+int gpx_chol_free(gpx_chol* f) {
+    if (!f) return GPX_OK;
+    (void)hipSetDevice(f->dev);
+    f->L.release();
+    f->Wd.release();
+    delete f;
+    return GPX_OK;
+}
+
 }  // extern "C"

@@ -32,8 +32,11 @@ MatrixXd Cov::dk_dhyp(const VectorXd& hyp, std::size_t idx, const MatrixXd& x1, 
 MatrixXd Cov::dk_dx1(const VectorXd& hyp, const VectorXd& x1, const MatrixXd& x2) const {
     MatrixXd one(_dim, 1);
     for (std::size_t i = 0; i < _dim; ++i) one(i, 0) = x1[i];
-    const MatrixXd K = k(hyp, one, x2);  // 1 x q
-    MatrixXd dK(_dim, x2.cols());
+    return dk_dx1(hyp, x1, x2, k(hyp, one, x2));  // CovSEard.cpp:28-32
+}
+MatrixXd Cov::dk_dx1(const VectorXd& hyp, const VectorXd& x1, const MatrixXd& x2, const RowVectorXd& K) const {
+    if (K.rows() != 1 || K.cols() != x2.cols() || x1.size() != _dim) throw std::invalid_argument("Cov::dk_dx1: shape");
+    MatrixXd dK(_dim, x2.cols());  // CovSEard.cpp:33-40
     for (std::size_t b = 0; b < x2.cols(); ++b)
         for (std::size_t i = 0; i < _dim; ++i) dK(i, b) = K(0, b) * (inv_lscale2(hyp, i) * (x2(i, b) - x1[i]));
     return dK;
@@ -49,7 +52,9 @@ MatrixXd Cov::diag_dk_dhyp(const VectorXd& hyp, const MatrixXd& x) const {
     for (std::size_t j = 0; j < x.cols(); ++j) g(sf_index(), j) = v;
     return g;
 }
+MatrixXd Cov::diag_dk_dhyp(const VectorXd& hyp, const MatrixXd& x, const MatrixXd&) const { return diag_dk_dhyp(hyp, x); }
 MatrixXd Cov::diag_dk_dx1(const VectorXd&, const VectorXd&) const { return MatrixXd(_dim, 1); }
+MatrixXd Cov::diag_dk_dx1(const VectorXd& hyp, const VectorXd& x1, const RowVectorXd&) const { return diag_dk_dx1(hyp, x1); }
 
 std::pair<double, double> Cov::lscale_range(const MatrixXd& xs, std::size_t i) const {
     double lo = xs(i, 0), hi = xs(i, 0);

@@ -25,11 +25,17 @@ public:
     virtual MatrixXd dk_dhyp(const VectorXd& hyp, std::size_t idx, const MatrixXd& x1, const MatrixXd& x2,
                              const MatrixXd& K) const = 0;
     virtual MatrixXd dk_dx1(const VectorXd& hyp, const VectorXd& x1, const MatrixXd& x2) const;
+    // Cov/Cov.h:18 — the same from a kernel row K = k(x1, x2) (1 x q) that the caller already holds
+    virtual MatrixXd dk_dx1(const VectorXd& hyp, const VectorXd& x1, const MatrixXd& x2, const RowVectorXd& K) const;
     virtual std::pair<VectorXd, VectorXd> cov_hyp_range(const MatrixXd& xs, const VectorXd& ys) const = 0;
     virtual VectorXd default_hyp(const MatrixXd& xs, const VectorXd& ys) const = 0;
     virtual VectorXd diag_k(const VectorXd& hyp, const MatrixXd& x) const;
     virtual MatrixXd diag_dk_dhyp(const VectorXd& hyp, const MatrixXd& x) const;
+    // Cov/Cov.h:25,27 — overloads that take an already computed K; the SE kernels ignore it
+    // (CovSEard.cpp:85-103: the diagonal is sf2 whatever K holds)
+    virtual MatrixXd diag_dk_dhyp(const VectorXd& hyp, const MatrixXd& x, const MatrixXd& K) const;
     virtual MatrixXd diag_dk_dx1(const VectorXd& hyp, const VectorXd& x1) const;
+    virtual MatrixXd diag_dk_dx1(const VectorXd& hyp, const VectorXd& x1, const RowVectorXd& K) const;
 
 protected:
     virtual std::size_t sf_index() const = 0;
@@ -44,6 +50,7 @@ public:
     int abi_id() const override;
     std::size_t num_hyp() const override { return _dim + 1; }
     using Cov::dk_dhyp;
+    using Cov::dk_dx1;
     MatrixXd dk_dhyp(const VectorXd& hyp, std::size_t idx, const MatrixXd& x1, const MatrixXd& x2,
                      const MatrixXd& K) const override;
     std::pair<VectorXd, VectorXd> cov_hyp_range(const MatrixXd& xs, const VectorXd& ys) const override;
@@ -60,6 +67,7 @@ public:
     int abi_id() const override;
     std::size_t num_hyp() const override { return 2; }
     using Cov::dk_dhyp;
+    using Cov::dk_dx1;
     MatrixXd dk_dhyp(const VectorXd& hyp, std::size_t idx, const MatrixXd& x1, const MatrixXd& x2,
                      const MatrixXd& K) const override;
     std::pair<VectorXd, VectorXd> cov_hyp_range(const MatrixXd& xs, const VectorXd& ys) const override;

@@ -25,9 +25,13 @@ int main(int argc, char** argv) {
     }
     MatrixXd y(num_train, 1);
     for (long i = 0; i < num_train; ++i) y(i, 0) = train_y(i, 0);
+    // GPX_DEMO_FIXED=1 (not in the reference's CLI): set_fixed(true), i.e. train() only runs _setK at the start
+    // hypers, so that tests can pin the `pred` file at known hypers
+    const bool fixed = std::getenv("GPX_DEMO_FIXED") && std::getenv("GPX_DEMO_FIXED")[0] == '1';
     const auto t1 = std::chrono::high_resolution_clock::now();
 #if DEMO_MODEL == 0
     GP gp(train_x.leftCols(num_train), y, GP::COV_SE_ARD, GP::QR);
+    gp.set_fixed(fixed);
     const double nlz = gp.train();
 #else
 #if DEMO_MODEL == 1
@@ -36,9 +40,10 @@ int main(int argc, char** argv) {
 #else
     VFE gp(train_x.leftCols(num_train), y, GP::COV_SE_ARD, GP::QR);
     VectorXd init = gp.get_default_hyps();
-    init[init.size() - 2] = std::log(stddev(y.data(), y.rows()));  // test_vfe.cpp:38-39
+    init[init.size() - 2] = std::log(stddev(train_y.data(), train_y.rows()));  // test_vfe.cpp:38-39: std of the WHOLE train_y
 #endif
     gp.set_inducing(train_x.rightCols(num_inducing));
+    gp.set_fixed(fixed);
     const double nlz = gp.train(init);
 #endif
     const auto t2 = std::chrono::high_resolution_clock::now();

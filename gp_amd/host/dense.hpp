@@ -75,4 +75,7 @@ public:
     void appendCols(const MatrixXd& o) { v_.insert(v_.end(), o.v_.begin(), o.v_.end()); c_ += o.c_; if (!r_) r_ = o.r_; }
 };
 
+// Eigen::RowVectorXd in the reference's Cov interface (Cov/Cov.h:18,27): a 1 x q matrix here
+typedef MatrixXd RowVectorXd;
+
 }  // namespace gpx

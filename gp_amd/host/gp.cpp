@@ -7,6 +7,7 @@
 #include <fstream>
 #include <iostream>
 #include <limits>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 #include "../../include/gpx.h"
@@ -33,8 +34,8 @@ GP::GP(const MatrixXd& train_in, const MatrixXd& train_out, CovFunc cf, MatrixDe
       _cf(cf), _md(md), _cov(make_cov(train_in.rows(), cf)), _num_train(train_in.cols()), _noise_lb(1e-3),
       _dim(train_in.rows()), _num_hyp(_cov->num_hyp() + 2), _hyps_lb(_num_hyp), _hyps_ub(_num_hyp), _trained(false) {
     if (_num_train != train_out.rows()) throw std::invalid_argument("GP: train_in.cols() != train_out.rows()");
-    must(gpx_ctx_create(0, &_ctx), "ctx_create");
-    _set_hyp_range();
+    if (const char* e = std::getenv("GPX_DEVICE")) _device = std::atoi(e);   // one rank per GPU: e.g. LOCAL_RANK
+    _set_hyp_range();   // host only: the device context is created at the first evaluation (_upload)
 }
 GP::~GP() {
     delete _cov;
@@ -42,7 +43,12 @@ GP::~GP() {
 }
 int GP::_model() const { return GPX_MODEL_EXACT; }
 
+void GP::set_device(int device) {
+    if (_ctx) throw std::logic_error("GP::set_device: the device context already exists (call before the first evaluation)");
+    _device = device;
+}
 void GP::_upload() {
+    if (!_ctx) must(gpx_ctx_create(_device, &_ctx), "ctx_create");
     if (_uploaded) return;
     must(gpx_set_data(_ctx, _train_in.data(), _train_out.data(), (int64_t)_num_train, (int64_t)_dim), "set_data");
     _uploaded = true;
@@ -169,13 +175,14 @@ double GP::train(const VectorXd& init_hyps) {
     if (!std::isfinite(nlz)) _hyps = select_init_hyp(_num_hyp * 50, _hyps);
     if (!_fixhyps) {
         std::vector<double> lb = hyp2vec(_hyps_lb), ub = hyp2vec(_hyps_ub), hyp0 = hyp2vec(_hyps);
-        BoundedLBFGS opt(hyp0.size());
-        opt.set_maxeval(_max_eval);
-        opt.set_min_objective(&GP::_objective, this);
-        opt.set_lower_bounds(lb);
-        opt.set_upper_bounds(ub);
-        const OptResult r = opt.optimize(hyp0, nlz);
-        _last_status = r.status + " after " + std::to_string(r.evals) + " evaluations";
+        std::unique_ptr<IOptimizer> opt(make_optimizer(hyp0.size()));   // NLopt LD_SLSQP where built in (GP.cpp:231)
+        opt->set_maxeval(_max_eval);
+        opt->set_min_objective(&GP::_objective, this);
+        opt->set_lower_bounds(lb);
+        opt->set_upper_bounds(ub);
+        const OptResult r = opt->optimize(hyp0, nlz);
+        _last_evals = r.evals;
+        _last_status = r.status + " after " + std::to_string(r.evals) + " evaluations (" + opt->name() + ")";
         _hyps = vec2hyp(hyp0);
     }
     _setK();
@@ -209,12 +216,14 @@ VectorXd GP::select_init_hyp(std::size_t max_eval, const VectorXd& def_hyp) {
     }
     return best;
 }
-double GP::_likelihood_gradient_checking(const VectorXd& hyp, const VectorXd& grad) {
-    return check_gradient(hyp, 1e-3) + 0 * grad.size();
-}
+// GP.cpp:486-507: relative L2 error of the caller's analytic gradient against central differences (eps 1e-3)
+double GP::_likelihood_gradient_checking(const VectorXd& hyp, const VectorXd& grad) { return _gradient_error(hyp, grad, 1e-3); }
 double GP::check_gradient(const VectorXd& hyp, double epsi) {
     VectorXd g;
     _calcNegLogProb(hyp, g, true);
+    return _gradient_error(hyp, g, epsi);
+}
+double GP::_gradient_error(const VectorXd& hyp, const VectorXd& g, double epsi) {
     double num = 0, den = 0;
     for (std::size_t i = 0; i < _num_hyp; ++i) {
         VectorXd h = hyp;
@@ -403,8 +412,7 @@ MatrixXd read_matrix(const std::string& path) {
     return m;
 }
 void write_pred(const std::string& path, const VectorXd& mean, const VectorXd& s2) {
-    std::ofstream f(path);
-    f.precision(9);
+    std::ofstream f(path);   // default stream precision (6 significant digits), as `f << rec` in mygp.cpp:32-36
     for (std::size_t i = 0; i < mean.size(); ++i) f << mean[i] << " " << std::sqrt(s2[i]) << "\n";
 }
 

@@ -6,7 +6,8 @@
 //  * MatrixDecomp::QR selects the same Cholesky as ::Cholesky (SPD inputs).
 //  * _check_SPD's eigenvalue / |I - K K^-1| test (GP.cpp:445-461) is replaced by "every Cholesky
 //    pivot > 0"; the noise / jitter escalation loops are reproduced as coded.
-//  * train() uses the built-in bounded L-BFGS (optimizer.hpp) instead of NLopt LD_SLSQP, and
+//  * train() goes through the IOptimizer seam (optimizer.hpp): NLopt LD_SLSQP where <nlopt.hpp> exists at
+//    build time, else the built-in bounded L-BFGS (NLopt is not in this image), and
 //    select_init_hyp() (MVMO, an un-vendored submodule of the reference) falls back to a
 //    deterministic scan over the bounds' interior.  Same budgets (160/130/150 evaluations).
 //  * VFE::predict_with_grad / predict_s2_with_grad throw std::logic_error where the reference
@@ -45,7 +46,9 @@ protected:
     bool _trained;
     int _max_eval = 160;       // GP.cpp:232
     std::string _last_status;  // optimiser status of the last train()
-    gpx_ctx* _ctx = nullptr;
+    int _last_evals = 0;
+    gpx_ctx* _ctx = nullptr;   // created on _device at the first evaluation
+    int _device = 0;
     bool _uploaded = false;
 
     virtual int _model() const;  // GPX_MODEL_*
@@ -66,6 +69,7 @@ protected:
     double _hyp_sn2(const VectorXd& hyp) const;
     double _hyp_mean(const VectorXd& hyp) const;
     double _likelihood_gradient_checking(const VectorXd& hyp, const VectorXd& grad);
+    double _gradient_error(const VectorXd& hyp, const VectorXd& grad, double eps);
     static double _objective(const std::vector<double>& x, std::vector<double>& g, void* data);
 
 public:
@@ -87,6 +91,17 @@ public:
     void set_fixed(bool f) { _fixhyps = f; }
     void set_noise_free(bool flag);
     const std::string& last_optimizer_status() const { return _last_status; }
+    int last_optimizer_evals() const { return _last_evals; }
+    // GPU of this object (default 0, or the environment variable GPX_DEVICE): one rank per GPU sets its
+    // LOCAL_RANK here before the first evaluation
+    void set_device(int device);
+    int device() const { return _device; }
+    // the optimiser's box (GP.cpp:514-534) and the packing of the hyper vector it sees (GP.cpp:535-564:
+    // a noise-free GP drops the noise slot)
+    const VectorXd& hyp_lower_bounds() const { return _hyps_lb; }
+    const VectorXd& hyp_upper_bounds() const { return _hyps_ub; }
+    std::vector<double> pack_hyp(const VectorXd& hyp) const { return hyp2vec(hyp); }
+    VectorXd unpack_hyp(const std::vector<double>& v) const { return vec2hyp(v); }
 
     virtual double train(const VectorXd& init_hyps);
     double train();

@@ -6,29 +6,32 @@
 
 namespace gpx {
 
-static void run(const MatrixXd& a, int* spd, double* ld, double* B, int64_t nrhs, double* Inv) {
-    const int rc = gpx_chol_solve((int64_t)a.rows(), a.data(), spd, ld, B, nrhs, Inv);
-    if (rc) throw std::runtime_error("gpx_chol_solve failed with status " + std::to_string(rc));
+static void must(int rc, const char* what) {
+    if (rc) throw std::runtime_error(std::string("gpx: ") + what + " failed with status " + std::to_string(rc));
 }
+
+MatrixSolverLLT::~MatrixSolverLLT() { gpx_chol_free(_f); }
 
 void MatrixSolverLLT::decomp(const MatrixXd& x) {
     if (x.rows() != x.cols()) throw std::invalid_argument("MatrixSolver::decomp: not square");
-    _a = x;
+    gpx_chol_free(_f);
+    _f = nullptr;
+    _n = x.rows();
     int spd = 0;
     _logdet = std::numeric_limits<double>::quiet_NaN();
-    run(_a, &spd, &_logdet, nullptr, 0, nullptr);
+    must(gpx_chol_factor((int64_t)_n, x.data(), &_f, &spd, &_logdet), "chol_factor");
     _spd = spd != 0;
 }
 MatrixXd MatrixSolverLLT::solve(const MatrixXd& ys) const {
+    if (!_f || ys.rows() != _n) throw std::invalid_argument("MatrixSolver::solve: decomp() first, rows must match");
     MatrixXd x = ys;
-    int spd = 0;
-    run(_a, &spd, nullptr, x.data(), (int64_t)x.cols(), nullptr);
+    must(gpx_chol_solve_factored(_f, x.data(), (int64_t)x.cols()), "chol_solve");
     return x;
 }
 MatrixXd MatrixSolverLLT::inverse() const {
-    MatrixXd inv(_a.rows(), _a.cols());
-    int spd = 0;
-    run(_a, &spd, nullptr, nullptr, 0, inv.data());
+    if (!_f) throw std::invalid_argument("MatrixSolver::inverse: decomp() first");
+    MatrixXd inv(_n, _n);
+    must(gpx_chol_inverse_factored(_f, inv.data()), "chol_inverse");
     return inv;
 }
 

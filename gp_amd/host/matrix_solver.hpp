@@ -1,11 +1,14 @@
 // matrix_solver.hpp — MatrixSolver / MatrixSolverLLT / MatrixSolverQR (MatrixSolver.h:3-35).
 //
 // Seam (2) of the reference moves whole host matrices across the boundary; it is kept as an
-// API-compatible wrapper over gpx_chol_solve (blocked MFMA Cholesky on the device).  The QR
-// class maps to the same Cholesky: for the SPD matrices this library factors, log|det|, solve
-// and inverse agree with column-pivoted QR to rounding — deliberate.
+// API-compatible wrapper over the blocked MFMA Cholesky on the device: decomp() uploads and factors
+// ONCE (gpx_chol_factor), the factor stays in HBM, solve() / inverse() reuse it.  The QR class maps
+// to the same Cholesky: for the SPD matrices this library factors, log|det|, solve and inverse agree
+// with column-pivoted QR to rounding — deliberate.
 #pragma once
 #include "dense.hpp"
+
+struct gpx_chol;
 
 namespace gpx {
 
@@ -21,11 +24,16 @@ public:
 };
 
 class MatrixSolverLLT : public MatrixSolver {
-    MatrixXd _a;
+    gpx_chol* _f = nullptr;   // device-resident factor
+    std::size_t _n = 0;
     bool _spd = false;
     double _logdet = 0;
 
 public:
+    MatrixSolverLLT() {}
+    ~MatrixSolverLLT() override;
+    MatrixSolverLLT(const MatrixSolverLLT&) = delete;
+    MatrixSolverLLT& operator=(const MatrixSolverLLT&) = delete;
     void decomp(const MatrixXd&) override;
     bool check_SPD() const override { return _spd; }
     double log_det() const override { return _logdet; }

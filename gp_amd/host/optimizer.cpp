@@ -1,9 +1,17 @@
-// optimizer.cpp — projected L-BFGS with Armijo backtracking along the projection arc.
+// optimizer.cpp — projected L-BFGS with Armijo backtracking along the projection arc, and the NLopt adaptor.
 #include "optimizer.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <limits>
+#if defined(__has_include)
+#if __has_include(<nlopt.hpp>)
+#include <nlopt.hpp>
+#define GPX_HAVE_NLOPT 1
+#endif
+#endif
 
 namespace gpx {
 namespace {
@@ -103,6 +111,72 @@ OptResult BoundedLBFGS::optimize(std::vector<double>& x, double& fmin) {
     res.fbest = fbest;
     res.evals = evals;
     return res;
+}
+
+#ifdef GPX_HAVE_NLOPT
+namespace {
+class NloptSLSQP : public IOptimizer {
+    nlopt::opt opt_;
+    ObjectiveFn f_ = nullptr;
+    void* data_ = nullptr;
+    int evals_ = 0;
+    double fbest_ = std::numeric_limits<double>::infinity();
+    std::vector<double> xbest_;
+    static double tramp(const std::vector<double>& x, std::vector<double>& g, void* self) {
+        NloptSLSQP* o = static_cast<NloptSLSQP*>(self);
+        ++o->evals_;
+        double v;
+        try {
+            v = o->f_(x, g, o->data_);
+        } catch (const ForcedStop&) {
+            throw nlopt::forced_stop();  // GP.cpp:188-189
+        }
+        if (v < o->fbest_) { o->fbest_ = v; o->xbest_ = x; }
+        return v;
+    }
+
+public:
+    explicit NloptSLSQP(std::size_t n) : opt_(nlopt::LD_SLSQP, (unsigned)n) {}   // GP.cpp:231
+    const char* name() const override { return "NLopt LD_SLSQP"; }
+    void set_maxeval(int m) override { opt_.set_maxeval(m); }                   // GP.cpp:232
+    void set_min_objective(ObjectiveFn f, void* data) override {
+        f_ = f;
+        data_ = data;
+        opt_.set_min_objective(&NloptSLSQP::tramp, this);                       // GP.cpp:233
+    }
+    void set_lower_bounds(const std::vector<double>& lb) override { opt_.set_lower_bounds(lb); }   // GP.cpp:234
+    void set_upper_bounds(const std::vector<double>& ub) override { opt_.set_upper_bounds(ub); }   // GP.cpp:235
+    OptResult optimize(std::vector<double>& x, double& fmin) override {
+        OptResult r;
+        const std::vector<double> lb = opt_.get_lower_bounds(), ub = opt_.get_upper_bounds();
+        for (std::size_t i = 0; i < x.size(); ++i) x[i] = std::min(std::max(x[i], lb[i]), ub[i]);   // GP.cpp:208-215
+        try {
+            const nlopt::result res = opt_.optimize(x, fmin);                    // GP.cpp:257
+            r.status = res == nlopt::FTOL_REACHED ? "FTOL_REACHED" : res == nlopt::XTOL_REACHED ? "XTOL_REACHED"
+                     : res == nlopt::MAXEVAL_REACHED ? "MAXEVAL_REACHED" : res == nlopt::SUCCESS ? "SUCCESS" : "STOPVAL_OR_TIME";
+        } catch (const nlopt::forced_stop&) {
+            r.status = "FORCED_STOP";
+        } catch (const std::runtime_error&) {                                    // swallowed as GP.cpp:260-265
+            r.status = "FAILURE";
+        }
+        if (!xbest_.empty()) { x = xbest_; fmin = fbest_; }
+        r.fbest = fmin;
+        r.evals = evals_;
+        return r;
+    }
+};
+}  // namespace
+bool nlopt_available() { return true; }
+#else
+bool nlopt_available() { return false; }
+#endif
+
+IOptimizer* make_optimizer(std::size_t n) {
+#ifdef GPX_HAVE_NLOPT
+    const char* e = std::getenv("GPX_OPTIMIZER");
+    if (!(e && std::strcmp(e, "lbfgs") == 0)) return new NloptSLSQP(n);
+#endif
+    return new BoundedLBFGS(n);
 }
 
 }  // namespace gpx

@@ -4,8 +4,8 @@
 //     double f(const std::vector<double>& x, std::vector<double>& g, void* data)
 // (g.empty() => no gradient wanted; GP.cpp:186-191).  NLopt is not a dependency here.  The same
 // callback shape is kept and a built-in bound-constrained projected L-BFGS (with the reference's
-// maxeval budget and "best point seen" result) stands in; an NLopt adaptor can be plugged behind
-// the same interface by a user who has NLopt.
+// maxeval budget and "best point seen" result) stands in behind the IOptimizer seam; where <nlopt.hpp>
+// is present at build time an NLopt LD_SLSQP adaptor is compiled behind the same seam and preferred.
 #pragma once
 #include <string>
 #include <vector>
@@ -22,16 +22,29 @@ struct OptResult {
 
 struct ForcedStop {};  // thrown by a callback to stop the optimiser (nlopt::forced_stop's role, GP.cpp:188-189)
 
-class BoundedLBFGS {
+// The optimiser seam: what GP::train needs from nlopt::opt (GP.cpp:231-265).
+class IOptimizer {
+public:
+    virtual ~IOptimizer() {}
+    virtual const char* name() const = 0;
+    virtual void set_maxeval(int m) = 0;
+    virtual void set_min_objective(ObjectiveFn f, void* data) = 0;
+    virtual void set_lower_bounds(const std::vector<double>& lb) = 0;
+    virtual void set_upper_bounds(const std::vector<double>& ub) = 0;
+    // minimises from x (clamped into the bounds); on return x is the best point evaluated
+    virtual OptResult optimize(std::vector<double>& x, double& fmin) = 0;
+};
+
+class BoundedLBFGS : public IOptimizer {
 public:
     explicit BoundedLBFGS(std::size_t n) : n_(n), lb_(n, -1e300), ub_(n, 1e300) {}
-    void set_maxeval(int m) { maxeval_ = m; }
-    void set_min_objective(ObjectiveFn f, void* data) { f_ = f; data_ = data; }
-    void set_lower_bounds(const std::vector<double>& lb) { lb_ = lb; }
-    void set_upper_bounds(const std::vector<double>& ub) { ub_ = ub; }
+    const char* name() const override { return "built-in bounded L-BFGS"; }
+    void set_maxeval(int m) override { maxeval_ = m; }
+    void set_min_objective(ObjectiveFn f, void* data) override { f_ = f; data_ = data; }
+    void set_lower_bounds(const std::vector<double>& lb) override { lb_ = lb; }
+    void set_upper_bounds(const std::vector<double>& ub) override { ub_ = ub; }
     void set_ftol_rel(double t) { ftol_rel_ = t; }
-    // minimises from x (clamped into the bounds); on return x is the best point evaluated
-    OptResult optimize(std::vector<double>& x, double& fmin);
+    OptResult optimize(std::vector<double>& x, double& fmin) override;
 
 private:
     std::size_t n_;
@@ -41,5 +54,12 @@ private:
     int maxeval_ = 160;
     double ftol_rel_ = 1e-10;
 };
+
+// nlopt::opt(nlopt::LD_SLSQP, n) exactly as GP.cpp:231-238 sets it up; compiled only where <nlopt.hpp> exists
+// (link with -lnlopt).  A callback that throws ForcedStop is translated to nlopt::forced_stop and back.
+bool nlopt_available();
+// The optimiser GP::train uses: NLopt LD_SLSQP when this library was built with NLopt (and the environment
+// variable GPX_OPTIMIZER is not "lbfgs"), else the built-in bounded L-BFGS.  Caller owns the result.
+IOptimizer* make_optimizer(std::size_t n);
 
 }  // namespace gpx

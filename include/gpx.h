@@ -132,6 +132,15 @@ int gpx_cov_k(int cov, int64_t d, const double* hyp, const double* x1, int64_t p
 int gpx_chol_solve(int64_t n, const double* A, int* spd, double* logdet, double* B, int64_t nrhs,
                    double* Inv);
 
+/* The same with the factor kept ON THE DEVICE between MatrixSolver::decomp (MatrixSolver.cpp:9-12) and
+ * ::solve / ::inverse (MatrixSolver.cpp:13-16, 25-28): one O(n^3) factorisation per decomp(), not one per
+ * solve.  The handle belongs to the device that is current in gpx_chol_factor. */
+typedef struct gpx_chol gpx_chol;
+int gpx_chol_factor(int64_t n, const double* A, gpx_chol** out, int* spd, double* logdet);
+int gpx_chol_solve_factored(const gpx_chol* f, double* B, int64_t nrhs);
+int gpx_chol_inverse_factored(const gpx_chol* f, double* Inv);
+int gpx_chol_free(gpx_chol* f);
+
 #ifdef __cplusplus
 }
 #endif

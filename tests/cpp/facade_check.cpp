@@ -27,6 +27,7 @@ static void run(const char* tag, M& gp, const VectorXd& init, const MatrixXd& te
     const double nll = gp.train(init);
     std::snprintf(key, sizeof key, "%s_nll", tag); std::printf("%s %.17g\n", key, nll);
     std::fprintf(stderr, "%s optimizer status: %s\n", tag, gp.last_optimizer_status().c_str());
+    std::snprintf(key, sizeof key, "%s_evals", tag); std::printf("%s %d\n", key, gp.last_optimizer_evals());
     std::snprintf(key, sizeof key, "%s_hyp", tag); pv(key, gp.get_hyp());
     std::snprintf(key, sizeof key, "%s_mu", tag); pv(key, gp.batch_predict_y(test_x));
     std::snprintf(key, sizeof key, "%s_s2", tag); pv(key, gp.batch_predict_s2(test_x));

@@ -143,3 +143,26 @@ def test_exact_failure_and_noise_escalation(gpx):
     with pytest.raises(gpx.GpxError):
         gpx.Context().predict(X)                      # predict before _setK (assert(_trained), GP.cpp:275)
     ctx.close()
+
+
+def test_predict_shards_over_test_points(gpx):
+    """SURVEY.md §8(e) predict: test points are independent, so ranks shard X* with no collective — every shard of
+    the test set, predicted by its own context (one per rank), must reproduce the rows of the single-context answer
+    bit for bit (gp_amd.sharding.shard_range is bench.py's partition)."""
+    from gp_amd.sharding import shard_range
+    X, y, hyp, Xs = synth.make_problem(4, 900, 7, 301)
+    ref = gpx.Context()
+    ref.set_data(X, y)
+    ref.prepare(gpx.MODEL_EXACT, 0, hyp)
+    mu, s2, gmu, gs2 = ref.predict_with_grad(Xs)
+    for world in (2, 3):
+        for rank in range(world):
+            r0, r1 = shard_range(len(Xs), rank, world)
+            ctx = gpx.Context()
+            ctx.set_data(X, y)
+            ctx.prepare(gpx.MODEL_EXACT, 0, hyp)
+            m_r, s_r, gm_r, gs_r = ctx.predict_with_grad(Xs[r0:r1])
+            assert np.array_equal(m_r, mu[r0:r1]) and np.array_equal(s_r, s2[r0:r1])
+            assert np.array_equal(gm_r, gmu[r0:r1]) and np.array_equal(gs_r, gs2[r0:r1])
+            ctx.close()
+    ref.close()

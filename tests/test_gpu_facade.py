@@ -99,3 +99,31 @@ def test_demo_programs_write_pred(workdir, prog, args):
     assert "Negative log likelihood:" in out.stdout
     pred = np.loadtxt(workdir / "pred")
     assert pred.shape == (64, 2) and np.all(np.isfinite(pred)) and np.all(pred[:, 1] >= 0)
+
+
+@pytest.mark.parametrize("prog,args", [("gp", ["200"]), ("fitc", ["200", "32"]), ("vfe", ["200", "32"])])
+def test_demo_pred_file_matches_oracle_predictions_at_fixed_hypers(workdir, prog, args):
+    """`pred` (mygp.cpp:32-36, test_fitc.cpp:53-58, test_vfe.cpp:57-62: two columns mean, sqrt(s2), 6 significant
+    digits) against the oracle's _setK + predict at the demo's own start hypers (GPX_DEMO_FIXED=1 makes train() skip
+    the optimiser, GP.cpp:200-206), so the on-disk format either side of the path is pinned, not just its shape."""
+    g = np.load(GOLD)
+    n = 200
+    Xall = np.vstack([g["X"], g["U"]])
+    yall = np.concatenate([g["y"], np.zeros(M)])
+    X, y, U, Xs = Xall[:n], yall[:n], Xall[-32:], g["Xs"]
+    env = dict(os.environ, GPX_DEMO_FIXED="1")
+    out = subprocess.run([os.path.join(BIN, prog)] + args, cwd=workdir, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr
+    pred = np.loadtxt(workdir / "pred")
+    hyp = oracle.default_hyps(0, X, y)                              # GP.cpp:85-92
+    if prog == "gp":
+        mu, s2 = oracle.ExactState(0, X, y, hyp).predict(Xs)
+    else:
+        if prog == "vfe":
+            hyp[-2] = np.log(np.std(yall, ddof=1))                  # test_vfe.cpp:38-39: std of the WHOLE train_y file
+        mu, s2 = oracle.SparseState(prog, 0, X, y, U, 1e-8, hyp).predict(Xs)[:2]
+    assert pred.shape == (64, 2)
+    assert np.allclose(pred[:, 0], mu, rtol=1e-5, atol=0)           # 6 significant digits on disk
+    assert np.allclose(pred[:, 1], np.sqrt(s2), rtol=1e-5, atol=0)
+    txt = (workdir / "pred").read_text().split()
+    assert max(len(t.replace("-", "").replace(".", "").lstrip("0")) for t in txt if "e" not in t) <= 6

@@ -1,0 +1,63 @@
+"""MLE driver parity (GP.cpp:177-272, FITC.cpp:32-108, VFE.cpp:31-108): the facade's train() on
+the GPU against the SAME optimiser object driven by the CPU oracle's objective (tests/cpp/mle_oracle_check.cpp),
+on the 256-row fixture of the reference's own data, same start point, same box, same evaluation budget.
+NLopt is not in this image, so both sides run the built-in bounded L-BFGS behind the IOptimizer seam; what is
+compared is the DRIVER (packing, bounds, start clamping, budget, best-point return) plus the objective's parity
+along a whole optimisation path: the same number of evaluations +- 2 and the final NLL within 1e-6 relative where
+the run converges inside the reference's budget (1e-4 where maxeval cuts it off)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "refdata_small.npz")
+N, M = 256, 32
+
+
+def parse(text):
+    r = {}
+    for line in text.splitlines():
+        tok = line.split()
+        if len(tok) >= 2:
+            try:
+                r[tok[0]] = np.array([float(t) for t in tok[1:]])
+            except ValueError:
+                r[tok[0]] = tok[1:]
+    return r
+
+
+def test_train_matches_the_oracle_driven_optimisation(tmp_path):
+    g = np.load(GOLD)
+    np.savetxt(tmp_path / "train_x", np.vstack([g["X"], g["U"]]), fmt="%.17g")
+    np.savetxt(tmp_path / "train_y", np.concatenate([g["y"], np.zeros(M)]), fmt="%.17g")
+    np.savetxt(tmp_path / "test_x", g["Xs"], fmt="%.17g")
+    exe = str(tmp_path / "mle_oracle_check")
+    host, orc = os.path.join(ROOT, "gp_amd"), os.path.join(ROOT, "oracle")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "mle_oracle_check.cpp"),
+                    "-L" + host, "-lgpxhost", "-lgpx", "-Wl,-rpath," + host, os.path.join(orc, "libgporacle.so"),
+                    "-Wl,-rpath," + orc], check=True, timeout=300)
+    env = dict(os.environ, GPX_OPTIMIZER="lbfgs")
+    cpu = subprocess.run([exe, str(N), str(M)], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert cpu.returncode == 0, cpu.stderr
+    gpu = subprocess.run([os.path.join(host, "host", "bin", "facade_check"), str(N), str(M), "0"], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert gpu.returncode == 0, gpu.stderr
+    c, q = parse(cpu.stdout), parse(gpu.stdout)
+    for tag in ("gp", "fitc", "vfe"):
+        f_c, f_g = c[f"{tag}_nll"][0], q[f"{tag}_nll"][0]
+        e_c, e_g = int(c[f"{tag}_evals"][0]), int(q[f"{tag}_evals"][0])
+        print(f"\n[mle {tag}] oracle-driven: NLL {f_c:.12g} after {e_c} evals ({c[f'{tag}_status'][0]}); "
+              f"GPU facade: NLL {f_g:.12g} after {e_g} evals; rel diff {abs(f_c - f_g) / abs(f_c):.2e}; "
+              f"start NLL {c[f'{tag}_nll0'][0]:.12g} / {q[f'{tag}_nll0'][0]:.12g}")
+        assert abs(c[f"{tag}_nll0"][0] - q[f"{tag}_nll0"][0]) <= 1e-9 * abs(c[f"{tag}_nll0"][0])
+        assert f_g <= q[f"{tag}_nll0"][0]
+        assert abs(e_c - e_g) <= 2
+        # 1e-6 where the optimisation CONVERGES inside the reference's budget (FITC 11, VFE 38 evaluations here).  The
+        # exact GP's 27-parameter ARD search is cut off by maxeval = 160 (GP.cpp:232) far from a stationary point: the
+        # two paths see objectives that differ in the 12th digit, take the same 160 evaluations, and stop ~1e-5 apart
+        # (measured 7.2e-6) — a property of a truncated quasi-Newton path, bounded here at 1e-4.
+        converged = c[f"{tag}_status"][0] in ("FTOL_REACHED", "XTOL_REACHED")
+        assert abs(f_c - f_g) <= (1e-6 if converged else 1e-4) * abs(f_c)
