@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     // base per operand that advances by one K tile per step (scalar ALU) plus ONE loop-invariant
     // 32-bit byte offset per thread.  Vector instructions issued next to the MFMAs of the co-resident
     // wave delay them, so the address arithmetic of the generic path below costs matrix-pipe time.
-    const bool interior = tfA && tfB && (klo + kt1 * BK <= g.K) && kt0 < kt1;
+    const bool interior = tfA && tfB && (klo + kt1 * BK <= g.K) && kt0 < kt1 && !(g.flags & GEMM_NO_FAST32);
     if (TM == 4 && TN == 4 && interior && !(g.flags & GEMM_NO_DLDS)) {
         // Direct-to-LDS loop: global_load_lds_dwordx4 writes 64 lanes x 16 B = 1 KB straight into LDS
         // (no staging registers, no ds_write, no address VALU beyond one add per load), two LDS stages,
@@ -487,6 +487,7 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     g.fastB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 2 == 0);
     const TilePlan plan = plan_tiles(M, N, flags, splitk, kscale != nullptr);
     static_cast<TileOrder&>(g) = plan.main;
+    if (!gemm_lane_offsets_fit_32bit(lda, a_kc != 0) || !gemm_lane_offsets_fit_32bit(ldb, b_kc != 0)) g.flags |= GEMM_NO_FAST32;
     const int bt = plan.bt;
     const bool band = plan.band;
     const long grid = plan.grid;
@@ -518,6 +519,7 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     if (band) {
         GemmArgs b = g;
         static_cast<TileOrder&>(b) = plan.band_order;
+        b.flags |= g.flags & GEMM_NO_FAST32;
         launch<2, 2>(st, a_kc, b_kc, b, (int)plan.band_grid);
     }
     if (g.splitk > 1) {

@@ -130,6 +130,15 @@ GPX_HD inline bool tile_of_block(const TileOrder& g, int block, int& bi, int& bj
     return true;
 }
 
+// The interior K loops of gemm_kernel address an operand tile as a 64-bit scalar base plus ONE 32-bit byte offset
+// per lane: up to 31 rows of ld doubles for a K-contiguous operand (127 rows for its L2 warm-up load), up to 7
+// k-rows plus 128 B for an M/N-contiguous one.  False: the offsets would wrap, the launch must take the generic
+// 64-bit path (GEMM_NO_FAST32).
+inline bool gemm_lane_offsets_fit_32bit(long ld, bool k_contiguous) {
+    const double rows = k_contiguous ? 127.0 : 7.0;
+    return (rows * (double)ld + 128.0) * 8.0 < 4294967296.0;
+}
+
 struct TilePlan {
     TileOrder main;
     long grid;

@@ -68,6 +68,13 @@ static int check(const char* name, long M, long N, int flags, int splitk) {
 
 int main() {
     int fails = 0;
+    // 32-bit lane offsets of the interior loops: the bench shapes fit, an n = 17M-row K-contiguous operand does not
+    const bool off_ok = gemm_lane_offsets_fit_32bit(65536 + 16, false) && gemm_lane_offsets_fit_32bit((1L << 22) + 16, true) &&
+                        gemm_lane_offsets_fit_32bit((1L << 22) + 16, false) && !gemm_lane_offsets_fit_32bit(1L << 23, true) &&
+                        !gemm_lane_offsets_fit_32bit(17400000L, true) && gemm_lane_offsets_fit_32bit(17400000L, false) &&
+                        !gemm_lane_offsets_fit_32bit(80000000L, false);
+    std::printf("case lane_offsets_32bit %s M=0 N=0 flags=0 splitk=0\n", off_ok ? "ok" : "FAIL");
+    fails += off_ok ? 0 : 1;
     const long sizes[] = {64, 200, 1024, 2048, 2434, 4096, 4166, 8192, 9000, 16384, 17500, 32768};
     for (long n : sizes) {
         fails += check("full", n, n, 0, 1);
