@@ -280,13 +280,14 @@ def pmc_traffic():
         path = os.path.join(ROOT, "profiles", dname, "exact_n65536_traffic.json")
         if not os.path.exists(path):
             continue
-        tot, cnt = 0.0, 0
+        tot, cnt, per_eval = 0.0, 0, 0.0
         for k, v in json.load(open(path)).items():
             if k.startswith("gemm_kernel<4, 4"):
                 tot += (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"]) * v["launches"]
                 cnt += v["launches"]
+                per_eval += v.get("launches_per_eval", v["launches"] / 2.0)   # the r01 passes ran two evaluations
         if cnt:
-            return tot / cnt / 1e9, cnt, dname
+            return tot / cnt / 1e9, per_eval, dname
     return None, None, None
 
 

@@ -1,5 +1,5 @@
 """The JSON line of bench.py, as committed beside the rocprofv3 summary of the same command
-(profiles/r01h_default/bench.json), carries every field of the driver's contract plus the `roofline` and
+(profiles/r02a_default/bench.json), carries every field of the driver's contract plus the `roofline` and
 `cpu_baseline` objects, and its numbers are consistent with one another."""
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r01h_default", "bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02a_default", "bench.json")) as f:
         lines = [l for l in f.read().splitlines() if l.strip()]
     assert len(lines) == 1            # stdout carries exactly one line
     return json.loads(lines[0])
@@ -34,8 +34,16 @@ def test_roofline_and_cpu_baseline_objects():
     # the kernel-only rate bounds the end-to-end rate from above; both stay below the bare MFMA loop
     assert d["algorithmic_tflops_per_gpu"] < r["achieved"] < d["measured_bare_mfma_f64_tflops"] <= 78.6 * 1.01
     assert abs(r["algorithmic_flops_per_eval"] / 65536.0 ** 3 - 1.0) < 0.01   # n^3 flops per evaluation
+    # traffic (separate --pmc passes) and the live timing are about the SAME launch set: every 128x128-tile GEMM launch
+    assert r["traffic_launches_per_eval"] == r["launches_per_eval"] and r["traffic_source"].startswith("profiles/")
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "evals/s" and c["value"] > 0 and "n=4096" in c["sample"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "evals/s" and c["value"] > 0 and "n=3072" in c["sample"]
+    assert c["host_cores_available"] >= 1 and c["nproc"] >= 1
+    a = c["all_cores"]                                   # the all-cores leg with the core count stated
+    assert a["cores"] >= 1 and a["value"] > c["value"] and c["fitc_all_cores"]["value"] > 0
+    for h in d["hbm_rooflines"] + d["fitc"]["hbm_rooflines"]:   # the HBM-bound kernels, live HIP-event timing
+        assert h["bound"] == "hbm" and h["peak"] == 8000.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12 and 0 < h["frac"] < 1
+    assert d["exact8192"]["config"]["n"] == 8192 and d["exact8192"]["ms_per_step"] > 0
 
 
 def test_bench_gpus_n_starts_n_distinct_ranks_before_any_gpu_call():

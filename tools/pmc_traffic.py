@@ -11,6 +11,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+evals = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # evaluations the profiled command ran
 agg = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(lambda: defaultdict(int))
 for f in sorted(glob.glob(os.path.join(out, "*counter_collection.csv"))):
@@ -22,7 +23,7 @@ for f in sorted(glob.glob(os.path.join(out, "*counter_collection.csv"))):
 res = {}
 for name, cs in agg.items():
     n = max(cnt[name].values())
-    e = {"launches": n}
+    e = {"launches": n, "launches_per_eval": n / evals}
     if "FETCH_SIZE" in cs:
         e["fetch_bytes_per_launch_corrected"] = 2.0 * cs["FETCH_SIZE"] * 1024.0 / cnt[name]["FETCH_SIZE"]
     if "WRITE_SIZE" in cs:
