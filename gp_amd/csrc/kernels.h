@@ -39,7 +39,7 @@ long gpx_mfma_ldxa(long n);            // row stride of Xa  [dk][ldxa]
 long gpx_mfma_ldua(long m);            // row stride of Ua  [dk][ldua]; UaT is [ldua][n2]
 int gpx_mfma_dk(int d);
 int gpx_mfma_n2(int d);
-int gpx_mfma_trace_grid(long n, int d);
+int gpx_mfma_trace_grid(long n, int d, long m, bool two_weight_matrices);
 // centred, augmented operands from the scaled dimension-major inputs; Xa may be NULL (U side only)
 int gpx_mfma_prepare(hipStream_t st, const double* Xt, long ldx, long n, const double* Ut, long ldu, long m, int d,
                      double* cen, double* Xa, double* Ua, double* UaT);

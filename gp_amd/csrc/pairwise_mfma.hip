@@ -23,6 +23,7 @@
 // diagonal, as util.cpp:64-75 computes it).
 #include "gpx_internal.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -322,6 +323,239 @@ __global__ __launch_bounds__(256, 2) void trace_mfma_kernel(const MfmaPairArgs g
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// The same trace for the deep contractions (d > 30) as ONE 8-wave workgroup per CU: 128 rows per workgroup
+// (16 per wave), inducing points 32 at a time through a TWO-stage LDS ring that is filled by direct-to-LDS
+// loads (global_load_lds: no staging registers, which this kernel does not have) one tile ahead, one barrier
+// per tile, the next tile's weights requested right after that barrier so that nothing the tile computes with
+// is still in flight (hipcc drains every outstanding load at the first use of an ordinary load's result while a
+// direct-to-LDS load is pending).  The column sums stay in LDS for the whole launch.  The 4-wave kernel above
+// stages synchronously between two barriers and spends 60 % of its wave cycles waiting at d = 50.
+constexpr int CACC_MAX = 4096;   // inducing points (padded) whose column sums fit the LDS accumulator
+
+// sum over the 16 lanes of a DPP row, every lane ends with the same bits (ds_bpermute shuffles would put
+// four dependent LDS round trips per tile on the critical path of a wave that has one partner to hide them)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+    return x + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double x) {
+    x = dpp_add<0xB1>(x);    // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E>(x);    // quad_perm [2,3,0,1]
+    x = dpp_add<0x141>(x);   // row_half_mirror: the other quad of the half
+    return dpp_add<0x140>(x);  // row_mirror: the other half
+}
+
+template <int KK>
+__device__ __forceinline__ void dma_tile(const MfmaPairArgs& g, int b0, double* sU_s, double* sUT_s, double* sv_s, int wv, int lane) {
+    using C = Cfg<KK>;
+    constexpr int TB = 32, S1 = TB + 16;
+    constexpr int CH = (2 * C::N2 + 63) / 64;            // 256-B pieces per transposed row
+    constexpr int NQ = C::DK + CH * TB + 1;              // wave-loads per tile
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int ldua = (int)g.ldua;                        // <= CACC_MAX: every offset below fits 32 bits
+    const char* pU = reinterpret_cast<const char*>(g.Ua + b0) + lane * 4;
+    const char* pT = reinterpret_cast<const char*>(g.UaT + b0 * C::N2) + lane * 4;
+#pragma unroll
+    for (int i = 0; i < (NQ + 7) / 8; ++i) {
+        const int q = wv + 8 * i;   // wave-uniform
+        if (q < C::DK) {            // one row of image 1: 32 inducing points of augmented dimension q
+            __builtin_amdgcn_global_load_lds((gptr_t)(pU + (q * ldua) * 8), (lptr_t)(sU_s + q * S1), 4, 0, 0);
+        } else if (q < C::DK + CH * TB) {
+            const int r = q - C::DK, b = r / CH, h = r % CH;
+            if (CH * 64 == 2 * C::N2 || lane + 64 * h < 2 * C::N2)
+                __builtin_amdgcn_global_load_lds((gptr_t)(pT + (b * C::N2 + 32 * h) * 8), (lptr_t)(sUT_s + b * C::S2 + 32 * h), 4, 0, 0);
+        } else if (q == C::DK + CH * TB && g.v) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(g.v + b0) + lane * 4), (lptr_t)sv_s, 4, 0, 0);
+        }
+    }
+}
+
+template <int KK, bool HAS_M2>
+__global__ __launch_bounds__(512) void trace_mfma8_kernel(const MfmaPairArgs g) {
+    using C = Cfg<KK>;
+    constexpr int JT = C::JT, TB = 32, S1 = TB + 16, RB = 128, NWV = 8;
+    __shared__ __attribute__((aligned(16))) double sU[2][C::DK * S1];
+    __shared__ __attribute__((aligned(16))) double sUT[2][TB * C::S2];
+    __shared__ __attribute__((aligned(16))) double sv[2][TB];
+    __shared__ double csum[2][NWV][TB];
+    __shared__ double cacc[CACC_MAX];
+    __shared__ double red[NWV][C::N2 + 1];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, l4 = lane >> 4;
+    const int d = g.d;
+    double accS[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) accS[jt] = 0.0;
+    double accK = 0.0;
+    for (int i = threadIdx.x; i < CACC_MAX; i += 512) cacc[i] = 0.0;
+    if (threadIdx.x < 2 * TB) sv[threadIdx.x / TB][threadIdx.x % TB] = 0.0;   // stays zero when there is no u v^T term
+
+    const int ntile = (int)((g.m + TB - 1) / TB);
+    const int nmine = (int)blockIdx.x < g.nblk ? (g.nblk - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int m = (int)g.m;
+    // weights of tile tl of row block blk: this lane's 8 (b = b0 + 4 i + l4, a)
+    auto load_w = [&](int blk, int tl, double (&w1)[TB / 4], double (&w2)[TB / 4]) {
+        const int b0 = tl * TB;
+        const long a = (long)blk * RB + 16 * wv + l15;
+        const double* p1 = g.M1 + a + (long)(b0 + l4) * g.ldm1;
+        const double* p2 = HAS_M2 ? g.M2 + a + (long)(b0 + l4) * g.ldm2 : nullptr;
+        if ((long)blk * RB + RB <= g.n && b0 + TB <= m) {   // wave-uniform: the interior takes no per-load guard
+#pragma unroll
+            for (int i = 0; i < TB / 4; ++i) {
+                w1[i] = p1[(long)(4 * i) * g.ldm1];
+                w2[i] = HAS_M2 ? p2[(long)(4 * i) * g.ldm2] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TB / 4; ++i) {
+                const bool in = b0 + 4 * i + l4 < m && a < g.n;
+                w1[i] = in ? p1[(long)(4 * i) * g.ldm1] : 0.0;
+                w2[i] = (HAS_M2 && in) ? p2[(long)(4 * i) * g.ldm2] : 0.0;
+            }
+        }
+    };
+    double wc1[TB / 4], wc2[TB / 4], wn1[TB / 4], wn2[TB / 4];
+    double xf[KK];
+    double c1a = 1.0, c2a = 1.0, ua = 0.0;
+    v4d acc2[JT];
+    __syncthreads();   // cacc / sv initialised before the first direct-to-LDS load may land in sv
+    int blk = blockIdx.x, tl = 0, st = 0;   // row block, tile and LDS stage of the current iteration
+    if (nmine > 0) {
+        dma_tile<KK>(g, 0, sU[0], sUT[0], sv[0], wv, lane);
+        load_w(blk, 0, wc1, wc2);
+    }
+    for (int k = 0; k < nmine;) {
+        const int b0 = tl * TB;
+        if (tl == 0) {   // new row block: X fragments, row coefficients, fresh accumulators
+            const long a0 = (long)blk * RB + 16 * wv + l15;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) xf[kk] = g.Xa[(long)(4 * kk + l4) * g.ldxa + a0];
+            const bool in = a0 < g.n;
+            c1a = (in && g.c1) ? g.c1[a0] : 1.0;
+            c2a = (HAS_M2 && in && g.c2) ? g.c2[a0] : 1.0;
+            ua = (in && g.u) ? g.u[a0] : 0.0;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) acc2[jt] = (v4d){0, 0, 0, 0};
+        }
+        __syncthreads();   // this tile has landed (the barrier drains this wave's loads); stage st ^ 1 and csum[st] are free
+        if ((k > 0 || tl > 0) && threadIdx.x < TB) {   // column sums of the previous tile -> LDS accumulator
+            const int pt = tl > 0 ? tl - 1 : ntile - 1;
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) sum += csum[st ^ 1][w][threadIdx.x];
+            cacc[pt * TB + threadIdx.x] += sum;
+        }
+        const bool last_tile = tl == ntile - 1;
+        const int ntl = last_tile ? 0 : tl + 1, nblkidx = last_tile ? blk + (int)gridDim.x : blk, nk = last_tile ? k + 1 : k;
+        if (nk < nmine) {
+            dma_tile<KK>(g, ntl * TB, sU[st ^ 1], sUT[st ^ 1], sv[st ^ 1], wv, lane);
+            load_w(nblkidx, ntl, wn1, wn2);
+        }
+        const double* U1 = sU[st];
+        const double* U2 = sUT[st];
+        v4d D[TB / 16];
+#pragma unroll
+        for (int bt = 0; bt < TB / 16; ++bt) {
+            double u1[KK];   // the operands of one chain up front: their LDS latency is paid once per chain, not per MFMA
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) u1[kk] = U1[(4 * kk + l4) * S1 + 16 * bt + l15];
+            D[bt] = (v4d){0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) D[bt] = mfma(u1[kk], xf[kk], D[bt]);
+        }
+#pragma unroll
+        for (int bt = 0; bt < TB / 16; ++bt) {
+            double u2[4][JT];   // second-product operands of this 16-point group, in flight during the exps
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) u2[r][jt] = U2[(16 * bt + 4 * r + l4) * C::S2 + 16 * jt + l15];
+            double q[4], svl[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) svl[r] = sv[st][16 * bt + 4 * r + l4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int bl = 16 * bt + 4 * r + l4;
+                double w = c1a * wc1[4 * bt + r];
+                if (HAS_M2) w = fma(c2a, wc2[4 * bt + r], w);
+                w = fma(ua, svl[r], w);
+                if (b0 + bl >= m) w = 0.0;   // beyond m the operands are zero, K = sf2 there: the weight must vanish
+                q[r] = w * (g.sf2 * exp(-0.5 * fmax(D[bt][r], 0.0)));
+                const double cs = row16_sum(q[r]);
+                if (l15 == 0) csum[st][wv][bl] = cs;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc2[jt] = mfma(q[r], u2[r][jt], acc2[jt]);
+        }
+        if (last_tile) {   // end of the row block: acc2[jt][r] = row base + l4 + 4 r, column 16 jt + l15
+            const int jtd = d >> 4, ld = d & 15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double q1a = 0.0;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+                    if (jt == jtd) q1a = acc2[jt][r];
+                q1a = __shfl(q1a, (lane & 48) | ld, 64);
+                const long a = (long)blk * RB + 16 * wv + l4 + 4 * r;
+                if (l15 == 0) accK += q1a;
+                double x[JT];   // all loads of the row first: one wait, not JT
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    const int c = 16 * jt + l15;
+                    x[jt] = g.Xa[(long)(c < d ? c : 0) * g.ldxa + a];
+                }
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    const double t = fma(x[jt], fma(x[jt], q1a, acc2[jt][r]), accS[jt]);
+                    accS[jt] = (16 * jt + l15 < d) ? t : accS[jt];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TB / 4; ++i) {
+            wc1[i] = wn1[i];
+            wc2[i] = wn2[i];
+        }
+        tl = ntl;
+        blk = nblkidx;
+        k = nk;
+        st ^= 1;
+    }
+    __syncthreads();
+    if (nmine > 0 && threadIdx.x < TB) {   // the last tile's column sums (st was flipped after it)
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) sum += csum[st ^ 1][w][threadIdx.x];
+        cacc[(ntile - 1) * TB + threadIdx.x] += sum;
+    }
+    __syncthreads();
+    for (long i = threadIdx.x; i < g.ldua; i += 512) g.cpart[(long)blockIdx.x * g.ldua + i] = cacc[i];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        double sum = accS[jt];
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (l4 == 0) red[wv][16 * jt + l15] = sum;
+    }
+    {
+        double sum = accK;
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        if (lane == 0) red[wv][C::N2] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x <= C::N2) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) sum += red[w][threadIdx.x];
+        g.spart[(long)blockIdx.x * (C::N2 + 1) + threadIdx.x] = sum;
+    }
+}
+
 // ---- operand preparation ----------------------------------------------------------------------------
 // cen[i] = mean over the m inducing points of the scaled coordinate i
 __global__ void centre_kernel(const double* __restrict__ Ut, long ldu, long m, double* __restrict__ cen) {
@@ -414,6 +648,16 @@ __global__ void trace_mfma_finish_kernel(const double* __restrict__ spart, int n
 #define GPX_TRACE_K1(K) trace_mfma_kernel<K, false, GPX_TRACE_NS(K)>
 #define GPX_TRACE_K2(K) trace_mfma_kernel<K, true, GPX_TRACE_NS(K)>
 
+#define GPX_KK8_CASE(M2, K, grid, st, args) \
+    case K: hipLaunchKernelGGL((trace_mfma8_kernel<K, M2>), dim3(grid), dim3(512), 0, st, args); break;
+#define GPX_KK8_SWITCH(M2, kk, grid, st, args)                                                                   \
+    switch (kk) {                                                                                                \
+        GPX_KK8_CASE(M2, 9, grid, st, args) GPX_KK8_CASE(M2, 10, grid, st, args) GPX_KK8_CASE(M2, 11, grid, st, args) \
+        GPX_KK8_CASE(M2, 12, grid, st, args) GPX_KK8_CASE(M2, 13, grid, st, args) GPX_KK8_CASE(M2, 14, grid, st, args) \
+        GPX_KK8_CASE(M2, 15, grid, st, args)                                                                      \
+        default: hipLaunchKernelGGL((trace_mfma8_kernel<16, M2>), dim3(grid), dim3(512), 0, st, args); break;     \
+    }
+
 inline int kk_of(int d) { return (d + 2 + 3) / 4; }
 inline int n2_of(int d) { return 16 * ((4 * kk_of(d) - 1 + 15) / 16); }
 
@@ -424,10 +668,17 @@ long gpx_mfma_ldxa(long n) { return (n + 127) / 128 * 128; }
 long gpx_mfma_ldua(long m) { return (m + 63) / 64 * 64; }
 int gpx_mfma_dk(int d) { return 4 * kk_of(d); }
 int gpx_mfma_n2(int d) { return n2_of(d); }
-static inline int trace_rows(int d) { return kk_of(d) <= 8 ? 128 : 64; }   // rows per workgroup of the trace kernel
-int gpx_mfma_trace_grid(long n, int d) {
-    const long nblk = (n + trace_rows(d) - 1) / trace_rows(d);
-    return (int)(nblk < 512 ? nblk : 512);   // 2 workgroups per CU x 256 CUs; a fixed function of (n, d): deterministic sums
+static bool g_no_wide = false;   // GPX_NO_WIDE_TRACE=1: keep the 4-wave trace kernel for d > 30 (A/B measurements)
+// the 8-wave kernel: deep contractions whose (padded) inducing set fits its LDS column-sum accumulator
+// (one weight matrix only: with two, its registers spill and the 4-wave kernel stays)
+static inline bool trace_wide(int d, long m, bool two) { return kk_of(d) > 8 && !two && gpx_mfma_ldua(m) <= CACC_MAX && !g_no_wide; }
+static inline int trace_rows(int d, long m, bool two) { return (kk_of(d) <= 8 || trace_wide(d, m, two)) ? 128 : 64; }   // rows per workgroup
+int gpx_mfma_trace_grid(long n, int d, long m, bool two) {
+    static const bool init = [] { const char* e = getenv("GPX_NO_WIDE_TRACE"); g_no_wide = e && e[0] == '1'; return true; }();
+    (void)init;
+    const long nblk = (n + trace_rows(d, m, two) - 1) / trace_rows(d, m, two);
+    const long cap = trace_wide(d, m, two) ? 256 : 512;   // workgroups resident at a time: 1 or 2 per CU x 256 CUs
+    return (int)(nblk < cap ? nblk : cap);           // a fixed function of (n, d, m): deterministic sums
 }
 
 int gpx_mfma_prepare(hipStream_t st, const double* Xt, long ldx, long n, const double* Ut, long ldu, long m, int d,
@@ -474,13 +725,16 @@ int gpx_mfma_pair_trace(hipStream_t st, const double* Xa, long n, const double* 
     g.M2 = w.M2; g.ldm2 = w.ldm2; g.c2 = w.c2;
     g.u = w.u; g.v = w.v;
     g.cpart = cpart; g.spart = spart;
-    const long nblk = (n + trace_rows(d) - 1) / trace_rows(d);
+    const bool two = w.M2 != nullptr;
+    const int grid = gpx_mfma_trace_grid(n, d, m, two), n2 = gpx_mfma_n2(d);
+    const long nblk = (n + trace_rows(d, m, two) - 1) / trace_rows(d, m, two);
     if (nblk > 0x7fffffffL) return GPX_ERR_ARG;
     g.nblk = (int)nblk;
-    const int grid = gpx_mfma_trace_grid(n, d), n2 = gpx_mfma_n2(d);
     HIP_TRY(hipMemsetAsync(cpart, 0, (size_t)grid * g.ldua * sizeof(double), st));
     const long slot = gpx_pair_prof_open(st, 1, 8.0 * (double)n * (double)m * (w.M2 ? 2.0 : 1.0));
-    if (w.M2) {
+    if (trace_wide(d, m, two)) {
+        GPX_KK8_SWITCH(false, kk_of(d), (unsigned)grid, st, g);
+    } else if (w.M2) {
         GPX_KK_SWITCH(GPX_TRACE_K2, kk_of(d), (unsigned)grid, st, g);
     } else {
         GPX_KK_SWITCH(GPX_TRACE_K1, kk_of(d), (unsigned)grid, st, g);

@@ -231,7 +231,7 @@ struct Sparse {
         ldm = gpx_ld(m);
         if (mfma()) {
             const long ldxa = gpx_mfma_ldxa(n), ldua = gpx_mfma_ldua(m);
-            const int dk = gpx_mfma_dk(d), n2 = gpx_mfma_n2(d), grid = gpx_mfma_trace_grid(n, d);
+            const int dk = gpx_mfma_dk(d), n2 = gpx_mfma_n2(d), grid = std::max(gpx_mfma_trace_grid(n, d, m, false), gpx_mfma_trace_grid(n, d, m, true));
             if ((rc = c->Xa.ensure(dk * ldxa)) || (rc = c->Ua.ensure(dk * ldua)) || (rc = c->UaT.ensure(ldua * n2)) ||
                 (rc = c->cen.ensure(GPX_MAX_DIM)) || (rc = c->cvec.ensure(ldua)))
                 return rc;
@@ -252,7 +252,7 @@ struct Sparse {
         if ((rc = c->Wd_u.ensure(wdn)) || (rc = c->Wd_A.ensure(wdn))) return rc;
         if ((rc = c->T.ensure(gpx_trtri_scratch(m) > 64 * mm ? gpx_trtri_scratch(m) : 64 * mm))) return rc;  // trtri scratch / split-K slabs
         for (int i = 0; i < 8; ++i)
-            if ((rc = c->vn[i].ensure(n)) || (rc = c->vm[i].ensure(m + 16))) return rc;
+            if ((rc = c->vn[i].ensure(n)) || (rc = c->vm[i].ensure(m + 80))) return rc;  // + 64: direct-to-LDS loads read whole 32-entry tiles
         if ((rc = c->red.ensure(m * m + m + GPX_MAX_DIM + 64))) return rc;
         if ((rc = c->r.ensure(n))) return rc;
         if ((rc = c->pred_tmp.ensure((long)PW * (nblk(n) > nblk(m * m) ? nblk(n) : nblk(m * m)) + 64))) return rc;
