@@ -37,7 +37,132 @@ struct GemmArgs : TileOrder {
     long slab;     // doubles between split-K slabs
     int fastA, fastB;  // base pointer and ld allow 16-B vector loads
     const double* kscale;  // optional: op(A)(m,k) is multiplied by kscale[k] on its way into the MFMAs (K-contiguous A only)
+    // optional row-dot epilogue (128-tiles, beta == 0, no split-K): per 64-column part p of the output
+    //   R1[p*ldr + m] = sum_{n in part} C(m,n) * E(m,n)   (E == nullptr: E = C, i.e. row sums of squares)
+    //   R2[p*ldr + m] = sum_{n in part} E(m,n) * evec[n]   (when E and evec are given)
+    // so that the row statistics of a tall-skinny product do not cost a pass of their own over it
+    const double* E; long lde;
+    const double* evec;
+    double* R1; double* R2; long ldr;
 };
+
+// the row-dot epilogue of one wave: acc[j][i][r] = C(m0 + wm + 16 i + l15, n0 + wn + 16 j + l4 + 4 r) / alpha
+// RD == 1: E = C (row sums of squares, R1 only); RD == 2: E, evec, R1 and R2 all given
+template <int TM, int TN, bool FULL, int RD>
+__device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const v4d (&acc)[TN][TM], int mb, int nb, int l15, int l4) {
+    double s1[TM], s2[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) s1[i] = s2[i] = 0.0;
+    // one running pointer per operand (the 16 i offsets are immediates): no per-element 64-bit address registers
+    const double* ep = (RD == 2 && FULL) ? g.E + (mb + l15) + (long)(nb + l4) * g.lde : nullptr;
+    const double* vp = (RD == 2 && FULL) ? g.evec + nb + l4 : nullptr;
+    const long estep = 4 * g.lde;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool nin = FULL || nb + 16 * j + l4 + 4 * r < g.N;
+            if (RD == 2) {
+                double e[TM], ev;
+                if (FULL) {
+                    ev = vp[16 * j + 4 * r];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) e[i] = ep[16 * i];
+                    ep += estep;
+                } else {   // edge tiles: clamped addresses and 0/1 masks instead of guarded loads (no divergent branches)
+                    const int n = nb + 16 * j + l4 + 4 * r;
+                    const double nmask = n < g.N ? 1.0 : 0.0;
+                    const double* col = g.E + (long)min(n, g.N - 1) * g.lde;
+                    ev = g.evec[min(n, g.N - 1)] * nmask;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int m = mb + 16 * i + l15;
+                        e[i] = col[min(m, g.M - 1)] * (m < g.M ? nmask : 0.0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    s1[i] = fma(g.alpha * acc[j][i][r], e[i], s1[i]);
+                    s2[i] = fma(e[i], ev, s2[i]);
+                }
+                if (r & 1) __builtin_amdgcn_sched_barrier(0);   // at most two columns of E in flight: all accumulators are live here
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const double c = nin ? g.alpha * acc[j][i][r] : 0.0;
+                    s1[i] = fma(c, c, s1[i]);
+                }
+            }
+        }
+    const long off = (long)(nb / (16 * TN)) * g.ldr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        double a = s1[i], b = s2[i];
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        if (RD == 2) {
+            b += __shfl_xor(b, 16, 64);
+            b += __shfl_xor(b, 32, 64);
+        }
+        const int m = mb + 16 * i + l15;
+        if (l4 == 0 && (FULL || m < g.M)) {
+            g.R1[off + m] = a;
+            if (RD == 2) g.R2[off + m] = b;
+        }
+    }
+}
+
+// full 128-tile of the RD == 2 variant: per 16-column group the 16 loads of E are issued first, the group's C values
+// are stored while they are in flight, then the two row dots are formed (separate store and dot passes leave the
+// matrix pipe idle for 64 load round trips in 8 batches per tile: Cu GEMM 29.8 -> 32.2 ms at n = 2^20)
+template <int TM, int TN>
+__device__ __forceinline__ void store_rowdot_full(const GemmArgs& g, const v4d (&acc)[TN][TM], double* Cb, int mb, int nb, int l15, int l4) {
+    double s1[TM], s2[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) s1[i] = s2[i] = 0.0;
+    const double* ep = g.E + (mb + l15) + (long)(nb + l4) * g.lde;
+    const double* vp = g.evec + nb + l4;
+    double* cp = Cb + (mb + l15) + (long)(nb + l4) * g.ldc;
+    const long estep = 4 * g.lde, cstep = 4 * g.ldc;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        double e[4][TM], ev[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ev[r] = vp[16 * j + 4 * r];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) e[r][i] = ep[16 * i];
+            ep += estep;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) cp[16 * i] = g.alpha * acc[j][i][r];
+            cp += cstep;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                s1[i] = fma(g.alpha * acc[j][i][r], e[r][i], s1[i]);
+                s2[i] = fma(e[r][i], ev[r], s2[i]);
+            }
+        __builtin_amdgcn_sched_barrier(0);   // one group of E in flight at a time: all accumulators are live here
+    }
+    const long off = (long)(nb / (16 * TN)) * g.ldr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        double a = s1[i], b = s2[i];
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 16, 64);
+        b += __shfl_xor(b, 32, 64);
+        if (l4 == 0) {
+            g.R1[off + mb + 16 * i + l15] = a;
+            g.R2[off + mb + 16 * i + l15] = b;
+        }
+    }
+}
 
 constexpr int BK = 16;
 
@@ -99,7 +224,7 @@ __device__ __forceinline__ double sfrag(const double* __restrict__ s, int row, i
     return KC ? s[row * (BK + 2) + k] : s[k * (BMN + 16) + row];
 }
 
-template <int TM, int TN, bool AKC, bool BKC>
+template <int TM, int TN, bool AKC, bool BKC, int RD = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int NT = 256;
     constexpr int BM = 32 * TM, BN = 32 * TN;
@@ -377,7 +502,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 
     // epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4) + 4r]
     double* Cb = g.C + (g.splitk > 1 ? (long)ks * g.slab : 0);
-    const bool plain = g.splitk > 1 || g.beta == 0.0;
+    const bool plain = RD != 0 || g.splitk > 1 || g.beta == 0.0;   // the row-dot variants are beta == 0 only: no old-value path in them
+    if (RD == 2 && m0 + BM <= g.M && n0 + BN <= g.N) {
+        store_rowdot_full<TM, TN>(g, acc, Cb, m0 + wm, n0 + wn, l15, l4);
+        return;
+    }
     if (m0 + BM <= g.M && n0 + BN <= g.N) {
         // full tile: no bounds tests; with beta != 0 the old values come in batches of TM*4 loads per
         // wait instead of one round trip per element
@@ -403,6 +532,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                     for (int i = 0; i < TM; ++i) cj[r * s4 + 16 * i] = g.alpha * acc[j][i][r] + g.beta * old[r][i];
             }
         }
+        if (RD) rowdot_epilogue<TM, TN, true, RD>(g, acc, m0 + wm, n0 + wn, l15, l4);
         return;
     }
 #pragma unroll
@@ -420,6 +550,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 }
             }
         }
+    if (RD && n0 + wn < g.N) rowdot_epilogue<TM, TN, false, RD>(g, acc, m0 + wm, n0 + wn, l15, l4);
 }
 
 __global__ void splitk_reduce_kernel(double* __restrict__ C, long ldc, const double* __restrict__ W,
@@ -470,8 +601,12 @@ double useful_flops(long M, long N, long K, int flags) {
 
 int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
               const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
-              int flags, int splitk, double* work, const double* kscale = nullptr) {
+              int flags, int splitk, double* work, const double* kscale = nullptr, const GemmRowdot* rd = nullptr) {
     if (M <= 0 || N <= 0) return GPX_OK;
+    if (rd && rd->R1) {
+        if (a_kc || b_kc || beta != 0.0 || splitk > 1 || (flags & (GEMM_LOWER | GEMM_TILE64)) || (rd->E && !(rd->evec && rd->R2)) || (!rd->E && (rd->evec || rd->R2))) return GPX_ERR_ARG;
+        flags |= GEMM_TILE128;   // the parts are the 64-column halves of 128-tiles
+    }
     if (kscale && (!a_kc || (reinterpret_cast<uintptr_t>(kscale) & 15))) return GPX_ERR_ARG;
     if (M > 0x7fffffffL - 256 || N > 0x7fffffffL - 256 || K > 0x7fffffffL - 256) return GPX_ERR_ARG;
     if ((flags & GEMM_LOWER) && M != N) return GPX_ERR_ARG;
@@ -483,6 +618,10 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
     g.alpha = alpha; g.beta = beta;
     g.kscale = kscale;
+    g.E = nullptr; g.lde = 0; g.evec = nullptr; g.R1 = g.R2 = nullptr; g.ldr = 0;
+    if (rd && rd->R1) {
+        g.E = rd->E; g.lde = rd->lde; g.evec = rd->evec; g.R1 = rd->R1; g.R2 = rd->R2; g.ldr = rd->ldr;
+    }
     g.fastA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 2 == 0);
     g.fastB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 2 == 0);
     const TilePlan plan = plan_tiles(M, N, flags, splitk, kscale != nullptr);
@@ -514,7 +653,9 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
             g_prof.skipped++;
         }
     }
-    if (bt == 128) launch<4, 4>(st, a_kc, b_kc, g, (int)grid);
+    if (g.R1 && g.E) hipLaunchKernelGGL((gemm_kernel<4, 4, false, false, 2>), dim3((unsigned)grid), dim3(256), 0, st, g);
+    else if (g.R1) hipLaunchKernelGGL((gemm_kernel<4, 4, false, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, g);
+    else if (bt == 128) launch<4, 4>(st, a_kc, b_kc, g, (int)grid);
     else launch<2, 2>(st, a_kc, b_kc, g, (int)grid);
     if (band) {
         GemmArgs b = g;
@@ -626,6 +767,11 @@ int gpx_gemm(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double 
              const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
              int flags) {
     return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, 1, nullptr);
+}
+
+int gpx_gemm_rowdot(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha, const double* A, long lda,
+                    const double* B, long ldb, double* C, long ldc, int flags, const GemmRowdot& rd) {
+    return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, 0.0, C, ldc, flags, 1, nullptr, nullptr, &rd);
 }
 
 int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,

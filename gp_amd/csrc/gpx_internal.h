@@ -53,6 +53,18 @@ int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, 
                     const double* A, long lda, const double* B, long ldb, double beta, double* C,
                     long ldc, int flags, double* work, long work_doubles, const double* kscale = nullptr);
 
+// C = alpha op(A) op(B)^T (128-tiles, no split-K) with a row-dot epilogue: per 64-column part p = n / 64 of the output
+//   R1[p*ldr + m] = sum_{n in part p} C(m,n) * E(m,n)     (E == NULL: E = C, the row sums of squares)
+//   R2[p*ldr + m] = sum_{n in part p} E(m,n) * evec[n]    (E, evec and R2 come together or not at all)
+// (ceil(N/64) parts, ldr >= M; every part of every row m < M is written, deterministically)
+struct GemmRowdot {
+    const double* E; long lde;
+    const double* evec;
+    double* R1; double* R2; long ldr;
+};
+int gpx_gemm_rowdot(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha, const double* A, long lda,
+                    const double* B, long ldb, double* C, long ldc, int flags, const GemmRowdot& rd);
+
 // per-launch HIP-event timing of GEMM launches with >= min_flops useful flops (bench.py roofline)
 int gpx_gemm_prof_begin(double min_flops, int max_launches);
 int gpx_gemm_prof_end(double* total_ms, double* total_flops, long* launches, double* skipped_flops);

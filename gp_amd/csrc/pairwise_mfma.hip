@@ -58,6 +58,21 @@ struct Cfg {
 
 __device__ __forceinline__ v4d mfma(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
+// sum over the 16 lanes of a DPP row, every lane ends with the same bits (ds_bpermute shuffles would put
+// four dependent LDS round trips per tile on the critical path of a wave that has one partner to hide them)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+    return x + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double x) {
+    x = dpp_add<0xB1>(x);    // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E>(x);    // quad_perm [2,3,0,1]
+    x = dpp_add<0x141>(x);   // row_half_mirror: the other quad of the half
+    return dpp_add<0x140>(x);  // row_mirror: the other half
+}
+
 // stage one tile of 64 inducing points: image 1 sU[c][b] (first product: A operand rows = b, k = c),
 // image 2 sUT[b][c] (second product: B operand k = b, columns = c)
 template <int KK, bool WITH_T>
@@ -258,10 +273,7 @@ __global__ __launch_bounds__(256, 2) void trace_mfma_kernel(const MfmaPairArgs g
                         cs += q[s][r];
                     }
                     // column sum over this wave's rows
-                    cs += __shfl_xor(cs, 1, 64);
-                    cs += __shfl_xor(cs, 2, 64);
-                    cs += __shfl_xor(cs, 4, 64);
-                    cs += __shfl_xor(cs, 8, 64);
+                    cs = row16_sum(cs);
                     if (l15 == 0) csum[wv][bl] = cs;
                 }
                 // second product: [Q(-2U~) | Q1] += Q * UaT, contraction over the 16 inducing points of this group
@@ -331,21 +343,6 @@ __global__ __launch_bounds__(256, 2) void trace_mfma_kernel(const MfmaPairArgs g
 // direct-to-LDS load is pending).  The column sums stay in LDS for the whole launch.  The 4-wave kernel above
 // stages synchronously between two barriers and spends 60 % of its wave cycles waiting at d = 50.
 constexpr int CACC_MAX = 4096;   // inducing points (padded) whose column sums fit the LDS accumulator
-
-// sum over the 16 lanes of a DPP row, every lane ends with the same bits (ds_bpermute shuffles would put
-// four dependent LDS round trips per tile on the critical path of a wave that has one partner to hide them)
-template <int CTRL>
-__device__ __forceinline__ double dpp_add(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
-    return x + __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row16_sum(double x) {
-    x = dpp_add<0xB1>(x);    // quad_perm [1,0,3,2]
-    x = dpp_add<0x4E>(x);    // quad_perm [2,3,0,1]
-    x = dpp_add<0x141>(x);   // row_half_mirror: the other quad of the half
-    return dpp_add<0x140>(x);  // row_mirror: the other half
-}
 
 template <int KK>
 __device__ __forceinline__ void dma_tile(const MfmaPairArgs& g, int b0, double* sU_s, double* sUT_s, double* sv_s, int wv, int lane) {

@@ -53,22 +53,18 @@ __global__ void sum_partials_kernel(const double* __restrict__ part, int nblk, d
 // ---- FITC row kernels (one thread per training row; consecutive rows -> coalesced columns) ------
 // Gamma, 1/Gamma, p = r/Gamma   (FITC.cpp:215-216, 253-254); diag(1/Gamma) Kxu is never formed: the
 // Gram products take 1/Gamma as the K-dimension scale of the GEMM and C is scaled per row where it is used
-__global__ __launch_bounds__(256) void fitc_gamma_kernel(long n, long m, const double* __restrict__ V, long ld,
+// vv = rowsum(V o V) arrives as per-64-column partial sums from the row-dot epilogue of the GEMM that formed V
+// (gemm_f64.hip), so V is not read again
+__global__ __launch_bounds__(256) void fitc_gamma_kernel(long n, int nparts, const double* __restrict__ vv, long ldr,
                                                          const double* __restrict__ r, double sn2, double sf2,
                                                          double* __restrict__ g, double* __restrict__ p,
                                                          double* __restrict__ part) {
     const long a = (long)blockIdx.x * 256 + threadIdx.x;
     double v[PW] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (a < n) {
-        double s0 = 0.0, s1 = 0.0;
-        long b = 0;
-        for (; b + 1 < m; b += 2) {
-            const double x0 = V[a + b * ld], x1 = V[a + (b + 1) * ld];
-            s0 = fma(x0, x0, s0);
-            s1 = fma(x1, x1, s1);
-        }
-        if (b < m) s0 = fma(V[a + b * ld], V[a + b * ld], s0);
-        const double Gam = (sn2 + sf2 - (s0 + s1)) / sn2;
+        double s = 0.0;
+        for (int q = 0; q < nparts; ++q) s += vv[(long)q * ldr + a];
+        const double Gam = (sn2 + sf2 - s) / sn2;
         const double ig = 1.0 / Gam;
         g[a] = ig;
         p[a] = ig * r[a];
@@ -80,33 +76,25 @@ __global__ __launch_bounds__(256) void fitc_gamma_kernel(long n, long m, const d
 }
 
 // With Cu = Kxu A^-1 (C = diag(g) Cu): c1 = rowsum(C o diag(g) Kxu) = g^2 rowsum(Cu o Kxu), q = g (Kxu a), pq = p - q,
-// w and the trace coefficients.  Kxu a (FITC.cpp:219-220's Kxu * A^-1 F) is formed in the same pass over Kxu
-// instead of a GEMV of its own (8.6 GB less traffic per evaluation at n = 2^20).
-__global__ __launch_bounds__(256) void fitc_rowstats_kernel(long n, long m, const double* __restrict__ Cu,
-                                                            const double* __restrict__ Kxu, long ld,
-                                                            const double* __restrict__ avec, const double* __restrict__ g,
+// w and the trace coefficients.  rowsum(Cu o Kxu) and Kxu a (FITC.cpp:219-220's Kxu * A^-1 F) arrive as per-64-column
+// partial sums from the row-dot epilogue of the GEMM that formed Cu: neither Cu nor Kxu is read again
+// (17.2 GB less traffic per evaluation at n = 2^20, m = 1024).
+__global__ __launch_bounds__(256) void fitc_rowstats_kernel(long n, int nparts, const double* __restrict__ ck,
+                                                            const double* __restrict__ ka, long ldr,
+                                                            const double* __restrict__ g,
                                                             const double* __restrict__ p, double sn2,
                                                             double* __restrict__ c2coef, double* __restrict__ ucoef,
                                                             double* __restrict__ wv, double* __restrict__ part) {
     const long a = (long)blockIdx.x * 256 + threadIdx.x;
     double v[PW] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (a < n) {
-        double s0 = 0.0, s1 = 0.0, k0 = 0.0, k1 = 0.0;
-        long b = 0;
-        for (; b + 1 < m; b += 2) {
-            const double x0 = Kxu[a + b * ld], x1 = Kxu[a + (b + 1) * ld];
-            s0 = fma(Cu[a + b * ld], x0, s0);
-            s1 = fma(Cu[a + (b + 1) * ld], x1, s1);
-            k0 = fma(x0, avec[b], k0);
-            k1 = fma(x1, avec[b + 1], k1);
+        double s = 0.0, k = 0.0;
+        for (int q = 0; q < nparts; ++q) {
+            s += ck[(long)q * ldr + a];
+            k += ka[(long)q * ldr + a];
         }
-        if (b < m) {
-            const double x0 = Kxu[a + b * ld];
-            s0 = fma(Cu[a + b * ld], x0, s0);
-            k0 = fma(x0, avec[b], k0);
-        }
-        const double c1 = g[a] * g[a] * (s0 + s1);
-        const double q = g[a] * (k0 + k1);
+        const double c1 = g[a] * g[a] * s;
+        const double q = g[a] * k;
         const double pq = p[a] - q;
         const double w = g[a] - c1 - pq * pq / sn2;
         wv[a] = w;
@@ -225,6 +213,17 @@ struct Sparse {
     HypView h;
 
     bool mfma() const { return c->mfma_pairwise && gpx_mfma_pair_supported(d); }
+    long nparts() const { return (m + 63) / 64; }   // 64-column parts of the GEMM row-dot epilogue
+    // V = Kxu Lu^-T with rowsum(V o V) from the epilogue, then Gamma (FITC.cpp:213-216)
+    int v_and_gamma(const double* Winv_u, const double* r, double sn2, double sf2, double* g, double* p) {
+        GemmRowdot rd = {};
+        rd.R1 = c->rowp1.p; rd.ldr = ldn;
+        int rc = gpx_gemm_rowdot(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, Winv_u, ldm, c->V.p, ldn, GEMM_KHI_N, rd);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fitc_gamma_kernel, dim3(nblk(n)), dim3(256), 0, st, n, (int)nparts(), c->rowp1.p, ldn, r, sn2, sf2, g, p,
+                           part());
+        return GPX_OK;
+    }
     int alloc(bool grad) {
         int rc;
         ldn = gpx_ld(n);
@@ -240,8 +239,8 @@ struct Sparse {
         const long nm = ldn * m, mm = ldm * m;
         if ((rc = c->Kxu.ensure(nm))) return rc;
         if (model == GPX_MODEL_FITC) {
-            if ((rc = c->V.ensure(nm))) return rc;
-            if (grad && ((rc = c->Bm.ensure(nm)) || (rc = c->Cm.ensure(nm)))) return rc;
+            if ((rc = c->V.ensure(nm)) || (rc = c->rowp1.ensure(nparts() * ldn))) return rc;
+            if (grad && ((rc = c->Bm.ensure(nm)) || (rc = c->Cm.ensure(nm)) || (rc = c->rowp2.ensure(nparts() * ldn)))) return rc;
         } else if (grad) {
             if ((rc = c->Cm.ensure(nm))) return rc;
         }
@@ -382,10 +381,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     HIP_TRY(hipMemsetAsync(redT, 0, 16 * sizeof(double), st));
     if (fitc) {
         // V = Kxu Lu^-T (FITC.cpp:213-215 via the factor: diag(Kxu Kuu^-1 Kux) = rowsum(V o V))
-        if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->Winv_u.p, ldm, 0.0, c->V.p, ldn, GEMM_KHI_N)))
-            return rc;
-        hipLaunchKernelGGL(fitc_gamma_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, c->V.p, ldn, c->r.p, h.sn2, h.sf2, g,
-                           p, s.part());
+        if ((rc = s.v_and_gamma(c->Winv_u.p, c->r.p, h.sn2, h.sf2, g, p))) return rc;
         s.finish_partials(n, redT, 3);  // sum log Gamma, r^T Gamma^-1 r, n_local
         if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, p, 0.0, redF))) return rc;  // F = Kux Gamma^-1 r
     } else {
@@ -471,12 +467,14 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         if ((rc = s.gram(c->Winv_u.p, c->Kuu_inv.p))) return rc;
         // C = Gamma^-1 Kxu A^-1 (FITC.cpp:262) and B = Kxu Kuu^-1 = V Lu^-1 (FITC.cpp:214)
         double* Cm = c->Cm.p;  // Cu = Kxu A^-1; C = diag(1/Gamma) Cu enters through per-row coefficients
-        if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->A_inv.p, ldm, 0.0, Cm, ldn, 0))) return rc;
+        GemmRowdot rd = {};   // rowsum(Cu o Kxu) and Kxu a leave the GEMM with Cu
+        rd.E = c->Kxu.p; rd.lde = ldn; rd.evec = a_vec; rd.R1 = c->rowp1.p; rd.R2 = c->rowp2.p; rd.ldr = ldn;
+        if ((rc = gpx_gemm_rowdot(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->A_inv.p, ldm, Cm, ldn, 0, rd))) return rc;
         double* c2coef = c->vn[3].p;
         double* ucoef = c->vn[4].p;
         double* wv = c->vn[5].p;
-        hipLaunchKernelGGL(fitc_rowstats_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, Cm, c->Kxu.p, ldn, a_vec, g, p, h.sn2,
-                           c2coef, ucoef, wv, s.part());
+        hipLaunchKernelGGL(fitc_rowstats_kernel, dim3(nblk(n)), dim3(256), 0, st, n, (int)s.nparts(), c->rowp1.p, c->rowp2.p, ldn,
+                           g, p, h.sn2, c2coef, ucoef, wv, s.part());
         s.finish_partials(n, redT + GPX_MAX_DIM + 8, 4);  // sum(g-c1), sum pq^2, sum pq, sum w
         // half of W_xu = C - (1/sn2) pq a^T - (1/sn2) diag(w) B, contracted with every dKxu at once
         ta.M1 = Cm; ta.ldm1 = ldn; ta.c1 = g;
@@ -584,10 +582,7 @@ int gpx_sparse_prepare(gpx_ctx* c, int model, int cov, const double* hyp, double
         if ((rc = s.kernels(kuu_add))) return rc;
         if (fitc) {
             if ((rc = s.inverse(c->Lu.p, c->Wd_u.p, c->Winv_u.p, nullptr, true))) return rc;
-            if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->Winv_u.p, ldm, 0.0, c->V.p, ldn, GEMM_KHI_N)))
-                return rc;
-            hipLaunchKernelGGL(fitc_gamma_kernel, dim3(nblk(n)), dim3(256), 0, st, n, m, c->V.p, ldn, c->r.p, h.sn2, h.sf2,
-                               c->vn[0].p, c->vn[1].p, s.part());
+            if ((rc = s.v_and_gamma(c->Winv_u.p, c->r.p, h.sn2, h.sf2, c->vn[0].p, c->vn[1].p))) return rc;
             if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, c->vn[1].p, 0.0, redF))) return rc;
             if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Kxu.p, ldn, c->Kxu.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p,
                                       c->T.cap, c->vn[0].p)))

@@ -121,6 +121,28 @@ def dgemm(A, B, C_in=None, a_kc=False, b_kc=False, alpha=1.0, beta=0.0, flags=0,
     return dC.to_numpy().reshape(N, M).T.copy()
 
 
+lib.gpx_dgemm_rowdot.argtypes = [_i64, _i64, _i64, _d, _vp, _i64, _vp, _i64, _vp, _i64, _i, _vp, _i64, _vp, _vp, _vp, _i64]
+
+
+def dgemm_rowdot(A, B, E=None, evec=None, alpha=1.0, flags=0):
+    """Test helper: C = alpha*A@B.T (A (M, K), B (N, K)) with the row-dot epilogue; returns C, R1 (parts, M) and
+    R2 (parts, M) or None."""
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    M, K = A.shape
+    N = B.shape[0]
+    parts = (N + 63) // 64
+    dA, dB = DeviceBuffer.from_numpy(colmajor(A)), DeviceBuffer.from_numpy(colmajor(B))
+    dC, dR1 = DeviceBuffer(M * N), DeviceBuffer(parts * M)
+    dE = DeviceBuffer.from_numpy(colmajor(E)) if E is not None else None
+    dv = DeviceBuffer.from_numpy(np.asarray(evec, dtype=np.float64)) if evec is not None else None
+    dR2 = DeviceBuffer(parts * M) if E is not None else None
+    check(lib.gpx_dgemm_rowdot(M, N, K, alpha, dA.ptr, M, dB.ptr, N, dC.ptr, M, flags, dE.ptr if dE else None, M,
+                               dv.ptr if dv else None, dR1.ptr, dR2.ptr if dR2 else None, M), "dgemm_rowdot")
+    Cm = dC.to_numpy().reshape(N, M).T.copy()
+    return Cm, dR1.to_numpy((parts, M)), (dR2.to_numpy((parts, M)) if dR2 else None)
+
+
 # ---- high-level API ---------------------------------------------------------------------------
 MODEL_EXACT, MODEL_FITC, MODEL_VFE = 0, 1, 2
 COV_SE_ARD, COV_SE_ISO = 0, 1

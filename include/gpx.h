@@ -39,6 +39,16 @@ int gpx_dgemm_kscale(int b_kc, int64_t M, int64_t N, int64_t K, double alpha, co
                      const double* kscale, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
                      int flags, double* work, int64_t work_doubles);
 
+/* C = alpha * A * B^T (both operands M/N-contiguous) together with the row statistics of the result, per 64-column
+ * part p = n / 64 (ceil(N/64) parts, ldr >= M, every part of every row written, deterministic):
+ *   R1[p*ldr + m] = sum_{n in part p} C(m,n) * E(m,n)     (E == NULL: E = C, row sums of squares)
+ *   R2[p*ldr + m] = sum_{n in part p} E(m,n) * evec[n]    (E, evec, R2 all given or all NULL)
+ * Replaces the separate passes diag(Kxu Kuu^-1 Kux) = rowsum(V o V) (FITC.cpp:215), rowsum(C o Kxu) and Kxu * a
+ * (FITC.cpp:219-220, 262-263): the statistics leave the GEMM that forms V / C in its epilogue. */
+int gpx_dgemm_rowdot(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
+                     int64_t ldb, double* C, int64_t ldc, int flags, const double* E, int64_t lde, const double* evec,
+                     double* R1, double* R2, int64_t ldr);
+
 /* No counterpart in the reference.  gpx_dgemm_splitk for callers that cannot allocate (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc): the split-K slab workspace is a
  * static device array of the library, GPX_NOALLOC_WORK_DOUBLES doubles (64 MiB) on every GPU the library

@@ -153,3 +153,36 @@ def test_gemm_kscale_weighted_gram(shape):
     if M == N:
         C = lib.dgemm(A, A, a_kc=True, b_kc=True, kscale=s, flags=lib.GEMM_LOWER, splitk_work=64 * M * N)
         assert np.max(np.abs(np.tril(C) - np.tril((A * s) @ A.T))) < 1e-11 * K ** 0.5 * 10
+
+
+@pytest.mark.parametrize("shape", [(256, 128, 64), (1000, 200, 96), (130, 65, 20), (4096, 1024, 1024), (517, 1, 33)])
+@pytest.mark.parametrize("with_e", [False, True])
+def test_gemm_rowdot_epilogue_ragged_shapes(shape, with_e):
+    """The row-dot epilogue (gpx_dgemm_rowdot: rowsum(V o V), rowsum(C o Kxu) and Kxu a of FITC.cpp:215-220, 262-263
+    leave the GEMM that forms V / C) against NumPy, full and edge tiles, per 64-column part; also with the triangular
+    K range the V product uses."""
+    lib = _lib()
+    M, N, K = shape
+    rng = np.random.default_rng(M + N + K)
+    A, B = rng.standard_normal((M, K)), rng.standard_normal((N, K))
+    E = rng.standard_normal((M, N)) if with_e else None
+    v = rng.standard_normal(N) if with_e else None
+    C, R1, R2 = lib.dgemm_rowdot(A, B, E, v, alpha=0.7)
+    ref = 0.7 * A @ B.T
+    assert np.max(np.abs(C - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))) * K
+    W = E if with_e else ref
+    parts = (N + 63) // 64
+    assert R1.shape == (parts, M)
+    for p in range(parts):
+        sl = slice(64 * p, min(N, 64 * p + 64))
+        r1 = np.sum(ref[:, sl] * W[:, sl], axis=1)
+        assert np.max(np.abs(R1[p] - r1)) <= 1e-11 * max(1.0, np.max(np.abs(r1))) * K
+        if with_e:
+            r2 = E[:, sl] @ v[sl]
+            assert np.max(np.abs(R2[p] - r2)) <= 1e-12 * max(1.0, np.max(np.abs(r2))) * 64
+    if not with_e and K == N:   # V = Kxu Lu^-T: B upper-triangular as an (N, K) operand = zero for k > n
+        Bt = np.tril(B)
+        C, R1, _ = lib.dgemm_rowdot(A, Bt, flags=lib.GEMM_KHI_N)
+        ref = A @ Bt.T
+        assert np.max(np.abs(C - ref)) <= 1e-12 * np.max(np.abs(ref)) * K
+        assert np.max(np.abs(R1.sum(axis=0) - np.sum(ref * ref, axis=1))) <= 1e-11 * np.max(np.sum(ref * ref, axis=1)) * K
