@@ -170,6 +170,214 @@ __global__ __launch_bounds__(256) void potrf_base_tile_kernel(double* __restrict
     }
 }
 
+// ---- factor AND invert one nb x nb block, nb <= 128, in ONE workgroup on the matrix cores ----------------
+// The base case of potrf_inv_rec.  The block lives in LDS (column-major, leading dimension 132) for the whole
+// kernel; 16 x 16 sub-blocks are the unit of work (v_mfma_f64_16x16x4_f64):
+//   for k = 0 .. nb/16 - 1:   wave 0 factors the diagonal sub-block in registers (one row per lane, pivots and
+//                             columns broadcast with v_readlane) and inverts it (one column per lane, L read as LDS
+//                             broadcasts);  panel  L_ik = S_ik W_kk^T  and trailing update  S_ij -= L_ik L_jk^T  are
+//                             one 4-MFMA chain per sub-block, spread over the 8 waves;  3 barriers per k.
+//   W = L^-1 by forward substitution per block column, W_ij = -W_ii sum_{k=j}^{i-1} L_ik W_kj, one block column
+//   per wave with no barrier at all: W_ij is stored in the (unused) upper block (j, i), so that L stays intact.
+// Replaces, per 128 rows, two launches of the 64 x 64 kernel above and four single-tile GEMM launches (74 us ->
+// see DESIGN.md): the serial chain of small launches is what bounds exact n <= 8192 and the replicated m x m
+// phase of the sparse models.  Contract as potrf_base_tile_kernel(..., wfull = 0): A's lower triangle <- L,
+// W (nb x nb) <- L^-1 with zeros above the diagonal, *info = 1 on a pivot <= 0 (Eigen::LLT NumericalIssue).
+constexpr int NBI = 128;       // rows of the base block
+constexpr int LDI = NBI + 4;   // LDS leading dimension (16-B aligned columns)
+constexpr int LDW = 17;        // leading dimension of the 16 x 16 diagonal inverses
+#ifdef GPX_BASE_TIMING             // tools/probe/base_probe.hip: 100 MHz time stamps of the kernel's phases
+__device__ long long g_base_t[64];
+#define BASE_STAMP(i) do { if (threadIdx.x == 0) g_base_t[i] = wall_clock64(); } while (0)
+#define BASE_ADD(i, t0) do { if (threadIdx.x == 0) g_base_t[i] += wall_clock64() - (t0); } while (0)
+#else
+#define BASE_STAMP(i) do { } while (0)
+#define BASE_ADD(i, t0) do { } while (0)
+#endif
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {   // lane: wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ v4d mfma16(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+__global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict__ A, long lda, int nb, double* __restrict__ W,
+                                                             long ldw, int* __restrict__ info) {
+    __shared__ __align__(16) double S[NBI * LDI];
+    __shared__ __align__(16) double Wd[NBI / 16][16 * LDW];
+    __shared__ double invd[NBI];   // 1 / l_jj
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, l4 = lane >> 4;
+    const int nblk = (nb + 15) / 16, np = 16 * nblk;
+    BASE_STAMP(0);
+#ifdef GPX_BASE_TIMING
+    if (threadIdx.x == 0) g_base_t[8] = g_base_t[9] = g_base_t[10] = g_base_t[11] = g_base_t[12] = g_base_t[13] = 0;
+    long long tph = 0;
+#endif
+    {   // lower triangle, identity padding, zeros above: all loads of a thread in flight together (clamped addresses,
+        // no divergent branches; a guarded loop pays one HBM round trip per element: 32 in a row)
+        double v[NBI * NBI / 512];
+#pragma unroll
+        for (int q = 0; q < NBI * NBI / 512; ++q) {
+            const int idx = tid + 512 * q, r = idx & (NBI - 1), c = idx >> 7;
+            v[q] = A[min(r, nb - 1) + (long)min(c, nb - 1) * lda];
+        }
+#pragma unroll
+        for (int q = 0; q < NBI * NBI / 512; ++q) {
+            const int idx = tid + 512 * q, r = idx & (NBI - 1), c = idx >> 7;
+            S[r + c * LDI] = (r < nb && c <= r) ? v[q] : (r == c ? 1.0 : 0.0);
+        }
+    }
+    bool bad = false;
+    for (int k = 0; k < nblk; ++k) {
+        const int o = 16 * k;
+        __syncthreads();   // S_kk carries every update of the steps before
+#ifdef GPX_BASE_TIMING
+        if (k == 0) BASE_STAMP(1);
+        tph = wall_clock64();
+#endif
+        if (wv == 0) {
+            // ---- Cholesky of the 16 x 16 diagonal sub-block: lane i (and its three copies) holds row i
+            double r[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) r[c] = S[(o + l15) + (o + c) * LDI];
+            double tl = 0.0;   // 1 / l_jj of this lane's row
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double d = readlane_f64(r[j], j);
+                bad = bad || !(d > 0.0);
+                // 1/sqrt(d) on the critical path of the whole block: hardware estimate t0 (>= 26 bits), then ONE third-order
+                // step t0 (1 + e/2 + 3 e^2/8), e = 1 - d t0^2 (error ~ e^3: full precision, two dependent operations less
+                // than two Newton steps)
+                double t = __builtin_amdgcn_rsq(d);
+                const double er = fma(-d * t, t, 1.0);
+                t = fma(t * er, fma(0.375, er, 0.5), t);
+                if (l15 == j) tl = t;
+                const double lij = r[j] * t;                    // column j of L (lane j: sqrt(d))
+                r[j] = lij;
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c) r[c] = fma(-lij, readlane_f64(lij, c), r[c]);
+            }
+#ifdef GPX_BASE_TIMING
+            BASE_ADD(11, tph);
+            long long tq = wall_clock64();
+#endif
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) S[(o + l15) + (o + c) * LDI] = (c <= l15) ? r[c] : 0.0;
+                invd[o + l15] = tl;
+            }
+#ifdef GPX_BASE_TIMING
+            BASE_ADD(12, tq);
+#endif
+        }
+        __syncthreads();
+#ifdef GPX_BASE_TIMING
+        BASE_ADD(8, tph);
+        tph = wall_clock64();
+#endif
+        // ---- panel: X L_kk^T = S_:k by forward substitution, one row of the panel per thread (L_kk as LDS broadcasts):
+        // no inverse of the diagonal sub-block on the critical path of the factorisation
+        {
+            const int row = o + 16 + tid;
+            if (row < np) {
+                double x[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) x[c] = S[row + (o + c) * LDI];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    x[j] *= invd[o + j];
+#pragma unroll
+                    for (int c = j + 1; c < 16; ++c) x[c] = fma(-x[j], S[(o + c) + (o + j) * LDI], x[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) S[row + (o + c) * LDI] = x[c];
+            }
+        }
+        __syncthreads();
+#ifdef GPX_BASE_TIMING
+        BASE_ADD(9, tph);
+        tph = wall_clock64();
+#endif
+        // ---- trailing update: S_ij -= L_ik L_jk^T for k < j <= i
+        const int t = nblk - k - 1;
+        for (int p = wv; p < t * (t + 1) / 2; p += 8) {
+            int i = 0, rem = p;   // p -> (i, j), row-major over the lower triangle of the t x t trailing blocks
+            while (rem > i) rem -= ++i;
+            const int bi = k + 1 + i, bj = k + 1 + rem;
+            v4d D;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) D[r] = S[(16 * bi + l4 + 4 * r) + (16 * bj + l15) * LDI];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                D = mfma16(-S[(16 * bi + l15) + (o + 4 * kk + l4) * LDI], S[(16 * bj + l15) + (o + 4 * kk + l4) * LDI], D);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(16 * bi + l4 + 4 * r) + (16 * bj + l15) * LDI] = D[r];
+        }
+        BASE_ADD(10, tph);
+    }
+    __syncthreads();
+    BASE_STAMP(2);
+    if (bad) *info = 1;
+    // ---- inverses of the diagonal sub-blocks, all at once (wave k: sub-block k): lane c solves L_kk w = e_c with L_kk
+    // as LDS broadcasts, right-looking so that two dependent operations per row are on the critical path
+    for (int k = wv; k < nblk; k += 8) {
+        const int o = 16 * k;
+        double w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = (i == l15) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            w[q] *= invd[o + q];
+#pragma unroll
+            for (int i = q + 1; i < 16; ++i) w[i] = fma(-S[(o + i) + (o + q) * LDI], w[q], w[i]);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Wd[k][i + l15 * LDW] = (i >= l15) ? w[i] : 0.0;
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int idx = tid; idx < NBI * np; idx += 512) {   // L
+        const int r = idx & (NBI - 1), c = idx >> 7;
+        if (r < nb && c <= r) A[r + (long)c * lda] = S[r + c * LDI];
+    }
+    BASE_STAMP(3);
+    // ---- W = L^-1: block column j on wave j; W_ij (i > j) goes to the upper block (j, i), L stays intact
+    for (int j = wv; j < nblk; j += 8) {
+        for (int i = j + 1; i < nblk; ++i) {
+            v4d D = {0, 0, 0, 0};
+            for (int q = j; q < i; ++q) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double b = (q == j) ? Wd[j][(4 * kk + l4) + l15 * LDW] : S[(16 * j + 4 * kk + l4) + (16 * q + l15) * LDI];
+                    D = mfma16(S[(16 * i + l15) + (16 * q + 4 * kk + l4) * LDI], b, D);
+                }
+            }
+            // -W_ii * D: D's rows (l4 + 4 r) are the contraction index of the second product, taken in that order
+            v4d R = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R = mfma16(-Wd[i][l15 + (l4 + 4 * r) * LDW], D[r], R);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(16 * j + l4 + 4 * r) + (16 * i + l15) * LDI] = R[r];
+        }
+    }
+    __syncthreads();
+    BASE_STAMP(4);
+#pragma unroll 4
+    for (int idx = tid; idx < NBI * nb; idx += 512) {
+        const int r = idx & (NBI - 1), c = idx >> 7;
+        const int br = r >> 4, bc = c >> 4;
+        double v = 0.0;
+        if (br == bc) v = Wd[br][(r & 15) + (c & 15) * LDW];                               // zero above its diagonal
+        else if (br > bc) v = S[(16 * bc + (r & 15)) + (16 * br + (c & 15)) * LDI];
+        if (r < nb) W[r + (long)c * ldw] = v;
+    }
+    BASE_STAMP(5);
+}
+
 // B (M x nb) <- B * W^T with W = inverse of a base block (lower): the TRSM X L^T = B
 __global__ __launch_bounds__(256) void trsm_right_base_kernel(double* __restrict__ B, long ldb, long M, int nb,
                                                               const double* __restrict__ Wd) {
@@ -303,15 +511,20 @@ int trtri_rec(hipStream_t st, long n, const double* L, long ldl, double* W, long
                     GEMM_KHI_M | GEMM_HEAVY_LAST);
 }
 
+inline long inv_split(long n) { return ((n / 2 + NBI - 1) / NBI) * NBI; }
+
 // Factor and invert in one recursion: on return the diagonal blocks of A hold those of L (the
 // off-diagonal blocks of A are NOT L) and W = L^-1.  L21 lives in W's (2,1) block until that block
-// is overwritten by W21, so there is no triangular solve and no small kernel besides the 64x64 base.
+// is overwritten by W21, so there is no triangular solve and no small kernel besides the base block.
+// (Running T = L21 W11 on a side stream beside the trailing recursion was measured and dropped: the compute-bound
+// side product holds every CU until it ends, equal or low stream priority alike, so the chain of small launches
+// it was meant to hide waits behind it: exact n = 8192 17.1 -> 23.2 ms.)
 int potrf_inv_rec(hipStream_t st, long n, double* A, long lda, double* W, long ldw, double* T, int* info) {
-    if (n <= NB) {
-        hipLaunchKernelGGL(potrf_base_tile_kernel, dim3(1), dim3(256), 0, st, A, lda, (int)n, W, ldw, 0, info);
+    if (n <= NBI) {
+        hipLaunchKernelGGL(potrf_inv_base_kernel, dim3(1), dim3(512), 0, st, A, lda, (int)n, W, ldw, info);
         return GPX_OK;
     }
-    const long n1 = split(n), n2 = n - n1;
+    const long n1 = inv_split(n), n2 = n - n1;
     double* W21 = W + n1;
     double* W22 = W + n1 + n1 * ldw;
     int rc = potrf_inv_rec(st, n1, A, lda, W, ldw, T, info);
@@ -372,10 +585,11 @@ int gpx_potrf_inv(hipStream_t st, long n, double* A, long lda, double* W, long l
     return GPX_OK;
 }
 
-long gpx_trtri_scratch(long n) {
+long gpx_trtri_scratch(long n) {   // covers gpx_trtri (64-row base) and gpx_potrf_inv (128-row base)
     if (n <= NB) return 16;
-    const long n1 = split(n), n2 = n - n1;
-    return gpx_ld(n2) * n1 + 16;
+    const long n1 = split(n), m1 = inv_split(n);
+    const long a = gpx_ld(n - n1) * n1 + 16, b = n > NBI ? gpx_ld(n - m1) * m1 + 16 : 16;
+    return a > b ? a : b;
 }
 
 int gpx_trtri(hipStream_t st, long n, const double* L, long ldl, const double* Wd, double* W, long ldw,

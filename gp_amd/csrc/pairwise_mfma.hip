@@ -649,6 +649,9 @@ __global__ void trace_mfma_finish_kernel(const double* __restrict__ spart, int n
     case K: hipLaunchKernelGGL((trace_mfma8_kernel<K, M2>), dim3(grid), dim3(512), 0, st, args); break;
 #define GPX_KK8_SWITCH(M2, kk, grid, st, args)                                                                   \
     switch (kk) {                                                                                                \
+        GPX_KK8_CASE(M2, 1, grid, st, args) GPX_KK8_CASE(M2, 2, grid, st, args) GPX_KK8_CASE(M2, 3, grid, st, args) \
+        GPX_KK8_CASE(M2, 4, grid, st, args) GPX_KK8_CASE(M2, 5, grid, st, args) GPX_KK8_CASE(M2, 6, grid, st, args) \
+        GPX_KK8_CASE(M2, 7, grid, st, args) GPX_KK8_CASE(M2, 8, grid, st, args)                                    \
         GPX_KK8_CASE(M2, 9, grid, st, args) GPX_KK8_CASE(M2, 10, grid, st, args) GPX_KK8_CASE(M2, 11, grid, st, args) \
         GPX_KK8_CASE(M2, 12, grid, st, args) GPX_KK8_CASE(M2, 13, grid, st, args) GPX_KK8_CASE(M2, 14, grid, st, args) \
         GPX_KK8_CASE(M2, 15, grid, st, args)                                                                      \
@@ -665,13 +668,21 @@ long gpx_mfma_ldxa(long n) { return (n + 127) / 128 * 128; }
 long gpx_mfma_ldua(long m) { return (m + 63) / 64 * 64; }
 int gpx_mfma_dk(int d) { return 4 * kk_of(d); }
 int gpx_mfma_n2(int d) { return n2_of(d); }
-static bool g_no_wide = false;   // GPX_NO_WIDE_TRACE=1: keep the 4-wave trace kernel for d > 30 (A/B measurements)
+static int g_wide_mode = 0;   // GPX_WIDE_TRACE=none|all: A/B measurements of the two trace kernels
 // the 8-wave kernel: deep contractions whose (padded) inducing set fits its LDS column-sum accumulator
 // (one weight matrix only: with two, its registers spill and the 4-wave kernel stays)
-static inline bool trace_wide(int d, long m, bool two) { return kk_of(d) > 8 && !two && gpx_mfma_ldua(m) <= CACC_MAX && !g_no_wide; }
+static inline bool trace_wide(int d, long m, bool two) {
+    if (gpx_mfma_ldua(m) > CACC_MAX || g_wide_mode == 1) return false;
+    if (g_wide_mode == 2) return kk_of(d) <= 8 || !two;
+    return kk_of(d) > 8 && !two;
+}
 static inline int trace_rows(int d, long m, bool two) { return (kk_of(d) <= 8 || trace_wide(d, m, two)) ? 128 : 64; }   // rows per workgroup
 int gpx_mfma_trace_grid(long n, int d, long m, bool two) {
-    static const bool init = [] { const char* e = getenv("GPX_NO_WIDE_TRACE"); g_no_wide = e && e[0] == '1'; return true; }();
+    static const bool init = [] {
+        const char* e = getenv("GPX_WIDE_TRACE");
+        g_wide_mode = !e ? 0 : (e[0] == 'n' ? 1 : (e[0] == 'a' ? 2 : 0));
+        return true;
+    }();
     (void)init;
     const long nblk = (n + trace_rows(d, m, two) - 1) / trace_rows(d, m, two);
     const long cap = trace_wide(d, m, two) ? 256 : 512;   // workgroups resident at a time: 1 or 2 per CU x 256 CUs
@@ -729,7 +740,9 @@ int gpx_mfma_pair_trace(hipStream_t st, const double* Xa, long n, const double* 
     g.nblk = (int)nblk;
     HIP_TRY(hipMemsetAsync(cpart, 0, (size_t)grid * g.ldua * sizeof(double), st));
     const long slot = gpx_pair_prof_open(st, 1, 8.0 * (double)n * (double)m * (w.M2 ? 2.0 : 1.0));
-    if (trace_wide(d, m, two)) {
+    if (trace_wide(d, m, two) && two) {
+        GPX_KK8_SWITCH(true, kk_of(d), (unsigned)grid, st, g);
+    } else if (trace_wide(d, m, two)) {
         GPX_KK8_SWITCH(false, kk_of(d), (unsigned)grid, st, g);
     } else if (w.M2) {
         GPX_KK_SWITCH(GPX_TRACE_K2, kk_of(d), (unsigned)grid, st, g);

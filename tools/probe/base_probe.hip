@@ -1,0 +1,49 @@
+// base_probe.hip — phase timing of the 128-row factor-and-invert base kernel (chol.hip) on one random SPD block.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGPX_BASE_TIMING -I gp_amd/csrc tools/probe/base_probe.hip gp_amd/csrc/gemm_f64.hip gp_amd/csrc/blas1.hip -o tools/probe/base_probe
+#include "../../gp_amd/csrc/chol.hip"
+#include <cstdlib>
+#include <vector>
+int main(int argc, char** argv) {
+    const int nb = argc > 1 ? atoi(argv[1]) : 128, ld = 144;
+    std::vector<double> B(nb * nb), A((size_t)ld * nb, 0.0);
+    srand(1);
+    for (auto& v : B) v = rand() / (double)RAND_MAX - 0.5;
+    for (int i = 0; i < nb; ++i)
+        for (int j = 0; j < nb; ++j) {
+            double s = i == j ? nb : 0.0;
+            for (int k = 0; k < nb; ++k) s += B[i + k * nb] * B[j + k * nb];
+            A[i + (size_t)j * ld] = s;
+        }
+    double *dA, *dW;
+    int* dinfo;
+    hipMalloc(&dA, sizeof(double) * ld * nb);
+    hipMalloc(&dW, sizeof(double) * ld * nb);
+    hipMalloc(&dinfo, sizeof(int));
+    hipMemset(dinfo, 0, sizeof(int));
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemcpy(dA, A.data(), sizeof(double) * ld * nb, hipMemcpyHostToDevice);
+        hipMemset(dW, 0, sizeof(double) * ld * nb);
+        hipLaunchKernelGGL(potrf_inv_base_kernel, dim3(1), dim3(512), 0, 0, dA, (long)ld, nb, dW, (long)ld, dinfo);
+        hipDeviceSynchronize();
+        long long t[64] = {0};
+#ifdef GPX_BASE_TIMING
+        hipMemcpyFromSymbol(t, HIP_SYMBOL(g_base_t), sizeof(t));
+#endif
+        auto us = [&](int a, int b) { return (t[b] - t[a]) * 0.01; };
+        printf("nb %d: load %.2f  factor %.2f (diag %.2f [chol %.2f write %.2f inv %.2f] panel %.2f trailing %.2f)  L store %.2f  inverse %.2f  W store %.2f  total %.2f us\n", nb,
+               us(0, 1), us(1, 2), t[8] * 0.01, t[11] * 0.01, t[12] * 0.01, t[13] * 0.01, t[9] * 0.01, t[10] * 0.01, us(2, 3), us(3, 4), us(4, 5), us(0, 5));
+    }
+    // check W L = I
+    std::vector<double> L((size_t)ld * nb), W((size_t)ld * nb);
+    hipMemcpy(L.data(), dA, sizeof(double) * ld * nb, hipMemcpyDeviceToHost);
+    hipMemcpy(W.data(), dW, sizeof(double) * ld * nb, hipMemcpyDeviceToHost);
+    double err = 0;
+    for (int i = 0; i < nb; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = 0;
+            for (int k = j; k <= i; ++k) s += W[i + (size_t)k * ld] * L[k + (size_t)j * ld];
+            err = fmax(err, fabs(s - (i == j ? 1.0 : 0.0)));
+        }
+    printf("max |W L - I| = %.3g\n", err);
+    return 0;
+}
