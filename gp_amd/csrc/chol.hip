@@ -8,6 +8,7 @@
 // one-workgroup kernel, and triangular solves against them are products with those inverses.
 #include "gpx_internal.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -174,13 +175,15 @@ __global__ __launch_bounds__(256) void potrf_base_tile_kernel(double* __restrict
 // The base case of potrf_inv_rec.  The block lives in LDS (column-major, leading dimension 132) for the whole
 // kernel; 16 x 16 sub-blocks are the unit of work (v_mfma_f64_16x16x4_f64):
 //   for k = 0 .. nb/16 - 1:   wave 0 factors the diagonal sub-block in registers (one row per lane, pivots and
-//                             columns broadcast with v_readlane) and inverts it (one column per lane, L read as LDS
-//                             broadcasts);  panel  L_ik = S_ik W_kk^T  and trailing update  S_ij -= L_ik L_jk^T  are
-//                             one 4-MFMA chain per sub-block, spread over the 8 waves;  3 barriers per k.
+//                             columns broadcast with v_readlane);  the panel below it is a forward substitution
+//                             X L_kk^T = S_:k with one row per thread (L_kk read as LDS broadcasts), so that no
+//                             inverse sits on the critical path;  the trailing update  S_ij -= L_ik L_jk^T  is one
+//                             4-MFMA chain per sub-block, spread over the 8 waves;  3 barriers per k.
+//   The inverses of the diagonal sub-blocks follow, all at once (one per wave, one column per lane).
 //   W = L^-1 by forward substitution per block column, W_ij = -W_ii sum_{k=j}^{i-1} L_ik W_kj, one block column
 //   per wave with no barrier at all: W_ij is stored in the (unused) upper block (j, i), so that L stays intact.
 // Replaces, per 128 rows, two launches of the 64 x 64 kernel above and four single-tile GEMM launches (74 us ->
-// see DESIGN.md): the serial chain of small launches is what bounds exact n <= 8192 and the replicated m x m
+// 49 us, phases: tools/probe/base_probe.hip): the serial chain of small launches is what bounds exact n <= 8192 and the replicated m x m
 // phase of the sparse models.  Contract as potrf_base_tile_kernel(..., wfull = 0): A's lower triangle <- L,
 // W (nb x nb) <- L^-1 with zeros above the diagonal, *info = 1 on a pivot <= 0 (Eigen::LLT NumericalIssue).
 constexpr int NBI = 128;       // rows of the base block
@@ -519,12 +522,18 @@ inline long inv_split(long n) { return ((n / 2 + NBI - 1) / NBI) * NBI; }
 // (Running T = L21 W11 on a side stream beside the trailing recursion was measured and dropped: the compute-bound
 // side product holds every CU until it ends, equal or low stream priority alike, so the chain of small launches
 // it was meant to hide waits behind it: exact n = 8192 17.1 -> 23.2 ms.)
+bool g_base64 = false;   // GPX_BASE64=1: the 64-row scalar base block and its split (A/B measurements)
+
 int potrf_inv_rec(hipStream_t st, long n, double* A, long lda, double* W, long ldw, double* T, int* info) {
-    if (n <= NBI) {
+    if (g_base64 && n <= NB) {
+        hipLaunchKernelGGL(potrf_base_tile_kernel, dim3(1), dim3(256), 0, st, A, lda, (int)n, W, ldw, 0, info);
+        return GPX_OK;
+    }
+    if (!g_base64 && n <= NBI) {
         hipLaunchKernelGGL(potrf_inv_base_kernel, dim3(1), dim3(512), 0, st, A, lda, (int)n, W, ldw, info);
         return GPX_OK;
     }
-    const long n1 = inv_split(n), n2 = n - n1;
+    const long n1 = g_base64 ? split(n) : inv_split(n), n2 = n - n1;
     double* W21 = W + n1;
     double* W22 = W + n1 + n1 * ldw;
     int rc = potrf_inv_rec(st, n1, A, lda, W, ldw, T, info);
@@ -579,6 +588,8 @@ int gpx_potrf(hipStream_t st, long n, double* A, long lda, double* Wd, int* info
 
 int gpx_potrf_inv(hipStream_t st, long n, double* A, long lda, double* W, long ldw, double* T, int* info) {
     if (n <= 0) return GPX_OK;
+    static const bool init = [] { const char* e = getenv("GPX_BASE64"); g_base64 = e && e[0] == '1'; return true; }();
+    (void)init;
     const int rc = potrf_inv_rec(st, n, A, lda, W, ldw, T, info);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());

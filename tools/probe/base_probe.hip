@@ -33,6 +33,50 @@ int main(int argc, char** argv) {
         printf("nb %d: load %.2f  factor %.2f (diag %.2f [chol %.2f write %.2f inv %.2f] panel %.2f trailing %.2f)  L store %.2f  inverse %.2f  W store %.2f  total %.2f us\n", nb,
                us(0, 1), us(1, 2), t[8] * 0.01, t[11] * 0.01, t[12] * 0.01, t[13] * 0.01, t[9] * 0.01, t[10] * 0.01, us(2, 3), us(3, 4), us(4, 5), us(0, 5));
     }
+    if (argc > 2) {   // accuracy on an ill-conditioned kernel matrix (nb <= 64): new and old base kernels against long double
+        const int n = nb <= 64 ? nb : 64;
+        std::vector<double> x(n), K((size_t)ld * n, 0.0);
+        for (auto& v : x) v = rand() / (double)RAND_MAX;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) K[i + (size_t)j * ld] = exp(-0.5 * (x[i] - x[j]) * (x[i] - x[j]) / 0.09) + (i == j ? atof(argv[2]) : 0.0);
+        // long double reference: L and W = L^-1
+        std::vector<long double> Lr(n * n, 0.0L), Wr(n * n, 0.0L);
+        for (int j = 0; j < n; ++j) {
+            long double d = K[j + (size_t)j * ld];
+            for (int k = 0; k < j; ++k) d -= Lr[j + k * n] * Lr[j + k * n];
+            Lr[j + j * n] = sqrtl(d);
+            for (int i = j + 1; i < n; ++i) {
+                long double v = K[i + (size_t)j * ld];
+                for (int k = 0; k < j; ++k) v -= Lr[i + k * n] * Lr[j + k * n];
+                Lr[i + j * n] = v / Lr[j + j * n];
+            }
+        }
+        for (int c = 0; c < n; ++c)
+            for (int i = c; i < n; ++i) {
+                long double v = i == c ? 1.0L : 0.0L;
+                for (int k = c; k < i; ++k) v -= Lr[i + k * n] * Wr[k + c * n];
+                Wr[i + c * n] = v / Lr[i + i * n];
+            }
+        for (int which = 0; which < 2; ++which) {
+            hipMemcpy(dA, K.data(), sizeof(double) * ld * n, hipMemcpyHostToDevice);
+            hipMemset(dW, 0, sizeof(double) * ld * nb);
+            if (which == 0) hipLaunchKernelGGL(potrf_inv_base_kernel, dim3(1), dim3(512), 0, 0, dA, (long)ld, n, dW, (long)ld, dinfo);
+            else hipLaunchKernelGGL(potrf_base_tile_kernel, dim3(1), dim3(256), 0, 0, dA, (long)ld, n, dW, (long)ld, 0, dinfo);
+            hipDeviceSynchronize();
+            std::vector<double> L((size_t)ld * n), W((size_t)ld * n);
+            hipMemcpy(L.data(), dA, sizeof(double) * ld * n, hipMemcpyDeviceToHost);
+            hipMemcpy(W.data(), dW, sizeof(double) * ld * n, hipMemcpyDeviceToHost);
+            long double el = 0, ew = 0, nl = 0, nw = 0;
+            for (int j = 0; j < n; ++j)
+                for (int i = j; i < n; ++i) {
+                    el = fmaxl(el, fabsl(L[i + (size_t)j * ld] - Lr[i + j * n]));
+                    nl = fmaxl(nl, fabsl(Lr[i + j * n]));
+                    ew = fmaxl(ew, fabsl(W[i + (size_t)j * ld] - Wr[i + j * n]));
+                    nw = fmaxl(nw, fabsl(Wr[i + j * n]));
+                }
+            printf("%s kernel: max|L - Lref|/max|L| = %.3Lg   max|W - Wref|/max|W| = %.3Lg\n", which ? "old 64-row" : "new", el / nl, ew / nw);
+        }
+    }
     // check W L = I
     std::vector<double> L((size_t)ld * nb), W((size_t)ld * nb);
     hipMemcpy(L.data(), dA, sizeof(double) * ld * nb, hipMemcpyDeviceToHost);
