@@ -452,41 +452,52 @@ __global__ __launch_bounds__(512) void trace_mfma8_kernel(const MfmaPairArgs g) 
         }
         const double* U1 = sU[st];
         const double* U2 = sUT[st];
-        v4d D[TB / 16];
-#pragma unroll
-        for (int bt = 0; bt < TB / 16; ++bt) {
+        // Both r2 chains first, then per 16-point group Q = W o K on the vector unit and the second product.  (An
+        // explicit MFMA / VALU interleave of the groups (sched_group_barrier pipeline) was measured: no gain, 52.5 vs
+        // 53.4 ms at d = 50.  PMC: MFMA busy 48 %, ~560 vector instructions per wave and tile of which ~210 fp64: the
+        // fp64 MFMA and the fp64 vector operations of a SIMD share its fp64 ALUs (same 78.6 TFLOP/s peak for both on
+        // gfx950), so their times add: 3712 + ~3000 cycles per wave and tile, two waves per SIMD = the measured 6.3 us.)
+        auto mfma1 = [&](int bt, v4d& Dg) {
             double u1[KK];   // the operands of one chain up front: their LDS latency is paid once per chain, not per MFMA
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) u1[kk] = U1[(4 * kk + l4) * S1 + 16 * bt + l15];
-            D[bt] = (v4d){0, 0, 0, 0};
+            Dg = (v4d){0, 0, 0, 0};
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) D[bt] = mfma(u1[kk], xf[kk], D[bt]);
-        }
-#pragma unroll
-        for (int bt = 0; bt < TB / 16; ++bt) {
-            double u2[4][JT];   // second-product operands of this 16-point group, in flight during the exps
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) u2[r][jt] = U2[(16 * bt + 4 * r + l4) * C::S2 + 16 * jt + l15];
-            double q[4], svl[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) svl[r] = sv[st][16 * bt + 4 * r + l4];
+            for (int kk = 0; kk < KK; ++kk) Dg = mfma(u1[kk], xf[kk], Dg);
+        };
+        auto expq = [&](int bt, const v4d& Dg, double (&q)[4]) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int bl = 16 * bt + 4 * r + l4;
                 double w = c1a * wc1[4 * bt + r];
                 if (HAS_M2) w = fma(c2a, wc2[4 * bt + r], w);
-                w = fma(ua, svl[r], w);
+                w = fma(ua, sv[st][bl], w);
                 if (b0 + bl >= m) w = 0.0;   // beyond m the operands are zero, K = sf2 there: the weight must vanish
-                q[r] = w * (g.sf2 * exp(-0.5 * fmax(D[bt][r], 0.0)));
-                const double cs = row16_sum(q[r]);
-                if (l15 == 0) csum[st][wv][bl] = cs;
+                q[r] = w * (g.sf2 * exp(-0.5 * fmax(Dg[r], 0.0)));
+                csum[st][wv][bl] = row16_sum(q[r]);   // the 16 lanes of a row hold the same sum: same value, same address
             }
+        };
+        auto mfma2 = [&](int bt, const double (&q)[4]) {
+            double u2[4][JT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) u2[r][jt] = U2[(16 * bt + 4 * r + l4) * C::S2 + 16 * jt + l15];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) acc2[jt] = mfma(q[r], u2[r][jt], acc2[jt]);
+        };
+        static_assert(TB == 32, "two groups per tile");
+        {
+            v4d D0, D1;
+            double q0[4], q1[4];
+            mfma1(0, D0);
+            mfma1(1, D1);
+            expq(0, D0, q0);
+            mfma2(0, q0);
+            expq(1, D1, q1);
+            mfma2(1, q1);
         }
         if (last_tile) {   // end of the row block: acc2[jt][r] = row base + l4 + 4 r, column 16 jt + l15
             const int jtd = d >> 4, ld = d & 15;
