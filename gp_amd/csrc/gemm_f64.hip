@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int LA = AKC ? BM * (BK + 2) : BK * (BM + 16);
     constexpr int LB = BKC ? BN * (BK + 2) : BK * (BN + 16);
     __shared__ __attribute__((aligned(16))) double smem[LA + LB];
-    __shared__ __attribute__((aligned(16))) double smem1[(TM == 4 && TN == 4) ? LA + LB : 2];  // 2nd stage (direct-to-LDS loop)
+    __shared__ __attribute__((aligned(16))) double smem1[LA + LB];  // 2nd stage (direct-to-LDS loop of the 128-tiles, ring loop of the 64-tiles)
     double* sA = smem;
     double* sB = smem + LA;
 
@@ -401,6 +401,80 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         };
         if (AKC && g.kscale != nullptr) run(std::true_type{});
         else run(std::false_type{});
+    } else if (interior && TM <= 2 && TN <= 2) {
+        // 64x64 tiles: the products of the factorisation chains below 2048 rows, a few tiles on a few CUs with nothing
+        // co-resident to hide a load behind.  One K step of MFMAs is 0.43 us, an L2 / HBM load takes longer, so the
+        // operand registers are a ring of TWO K tiles: the loads of tile kt + 2 are issued while tile kt is multiplied
+        // (measured 0.75 us per K step with a one-tile distance, i.e. 0.3 us of exposed latency per step).
+        const long k00 = klo + kt0 * BK;
+        const char* pa = reinterpret_cast<const char*>(g.A) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
+        const char* pb = reinterpret_cast<const char*>(g.B) + (BKC ? k00 + (long)n0 * g.ldb : n0 + k00 * g.ldb) * 8;
+        const long ia = (AKC ? (NT / 8) * g.lda : (2 * NT / BM) * g.lda) * 8;  // between a thread's consecutive loads
+        const long ib = (BKC ? (NT / 8) * g.ldb : (2 * NT / BN) * g.ldb) * 8;
+        const long ka = (AKC ? (long)BK : BK * g.lda) * 8;            // per K tile
+        const long kb = (BKC ? (long)BK : BK * g.ldb) * 8;
+        const unsigned ta = (unsigned)((AKC ? 2 * (tid & 7) + (long)(tid >> 3) * g.lda
+                                            : 2 * (tid % (BM / 2)) + (long)(tid / (BM / 2)) * g.lda) * 8);
+        const unsigned tb = (unsigned)((BKC ? 2 * (tid & 7) + (long)(tid >> 3) * g.ldb
+                                            : 2 * (tid % (BN / 2)) + (long)(tid / (BN / 2)) * g.ldb) * 8);
+        const bool scaled = AKC && g.kscale != nullptr;
+        const double* ps = scaled ? g.kscale + k00 + 2 * (tid & 7) : nullptr;
+        v2d ra1[NLA], rb1[NLB];
+        v2d rs = (v2d){1.0, 1.0}, rs1 = (v2d){1.0, 1.0};
+        auto fetch = [&](v2d (&xa)[NLA], v2d (&xb)[NLB], v2d& xs) {   // the tile pa / pb / ps point at, then advance
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) xa[i] = *reinterpret_cast<const v2d*>(pa + i * ia + ta);
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) xb[i] = *reinterpret_cast<const v2d*>(pb + i * ib + tb);
+            if (scaled) {
+                xs = *reinterpret_cast<const v2d*>(ps);
+                ps += BK;
+            }
+            pa += ka;
+            pb += kb;
+        };
+        // two LDS stages as well: tile kt + 1 is written to the other stage before tile kt is multiplied, ONE barrier per
+        // K step, and the 16 fragment reads of a step are issued together
+        auto stash = [&](double* st, v2d (&xa)[NLA], v2d (&xb)[NLB], v2d& xs, bool refill) {
+            if (scaled) {
+#pragma unroll
+                for (int i = 0; i < NLA; ++i) xa[i] = xa[i] * xs;
+            }
+            sstore<BM, AKC, NT>(st, xa);
+            sstore<BN, BKC, NT>(st + LA, xb);
+            if (refill) fetch(xa, xb, xs);
+        };
+        auto multiply = [&](const double* st) {
+            double fa[BK / 4][TM], fb[BK / 4][TN];
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[kk][i] = sfrag<BM, AKC>(st, wm + i * 16 + l15, kk * 4 + l4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[kk][j] = sfrag<BN, BKC>(st + LA, wn + j * 16 + l15, kk * 4 + l4);
+            }
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[kk][j], fa[kk][i], acc[j][i], 0, 0, 0);
+        };
+        fetch(ra, rb, rs);                              // tile kt0
+        if (kt0 + 1 < kt1) fetch(ra1, rb1, rs1);        // tile kt0 + 1
+        stash(smem, ra, rb, rs, kt0 + 2 < kt1);         // stage 0 <- tile kt0; ra <- tile kt0 + 2
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            if (kt + 1 < kt1) stash(smem1, ra1, rb1, rs1, kt + 3 < kt1);
+            multiply(smem);
+            __syncthreads();
+            if (kt + 1 < kt1) {
+                if (kt + 2 < kt1) stash(smem, ra, rb, rs, kt + 4 < kt1);
+                multiply(smem1);
+                __syncthreads();
+            }
+        }
     } else if (interior) {
         const long k00 = klo + kt0 * BK;
         const char* pa = reinterpret_cast<const char*>(g.A) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
@@ -656,7 +730,8 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     if (g.R1 && g.E) hipLaunchKernelGGL((gemm_kernel<4, 4, false, false, 2>), dim3((unsigned)grid), dim3(256), 0, st, g);
     else if (g.R1) hipLaunchKernelGGL((gemm_kernel<4, 4, false, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, g);
     else if (bt == 128) launch<4, 4>(st, a_kc, b_kc, g, (int)grid);
-    else launch<2, 2>(st, a_kc, b_kc, g, (int)grid);
+    else if (bt == 64) launch<2, 2>(st, a_kc, b_kc, g, (int)grid);
+    else launch<1, 1>(st, a_kc, b_kc, g, (int)grid);
     if (band) {
         GemmArgs b = g;
         static_cast<TileOrder&>(b) = plan.band_order;

@@ -142,7 +142,7 @@ inline bool gemm_lane_offsets_fit_32bit(long ld, bool k_contiguous) {
 struct TilePlan {
     TileOrder main;
     long grid;
-    int bt;              // 128 or 64
+    int bt;              // 128, 64 or 32
     bool band;           // LOWER product: second launch over the diagonal blocks (64-tiles)
     TileOrder band_order;
     long band_grid;
@@ -159,6 +159,10 @@ inline TilePlan plan_tiles(long M, long N, int flags, int splitk, bool has_kscal
     {
         const long t128 = ((M + 127) / 128) * ((N + 127) / 128) / ((flags & GEMM_LOWER) ? 2 : 1);
         if (t128 * (splitk > 1 ? splitk : 1) < 384) bt = 64;
+        // a 64x64 tile is bound by the matrix pipe of the ONE CU it runs on (0.43 us per 16-deep K step): products
+        // with at most 64 such tiles (the chains below 1024 rows) take 32x32 tiles, four times the CUs per product
+        const long t64 = ((M + 63) / 64) * ((N + 63) / 64) / ((flags & GEMM_LOWER) ? 2 : 1);
+        if (bt == 64 && t64 * (splitk > 1 ? splitk : 1) <= 64 && !(flags & GEMM_NO_TILE32)) bt = 32;
     }
     if (flags & GEMM_TILE64) bt = 64;
     if (flags & GEMM_TILE128) bt = 128;

@@ -21,7 +21,7 @@ _d = C.c_double
 
 GEMM_LOWER, GEMM_KLO_M, GEMM_KLO_N, GEMM_KHI_M, GEMM_KHI_N = 1, 2, 4, 8, 16
 GEMM_HEAVY_LAST, GEMM_TILE64, GEMM_TILE128 = 32, 64, 128
-GEMM_NO_SQUARES, GEMM_FORCE_SQUARES, GEMM_NO_BAND = 1024, 2048, 4096
+GEMM_NO_SQUARES, GEMM_FORCE_SQUARES, GEMM_NO_BAND, GEMM_NO_TILE32 = 1024, 2048, 4096, 8192
 
 
 class GpxError(RuntimeError):
