@@ -182,6 +182,9 @@ __global__ __launch_bounds__(256) void potrf_base_tile_kernel(double* __restrict
 //   The inverses of the diagonal sub-blocks follow, all at once (one per wave, one column per lane).
 //   W = L^-1 by forward substitution per block column, W_ij = -W_ii sum_{k=j}^{i-1} L_ik W_kj, one block column
 //   per wave with no barrier at all: W_ij is stored in the (unused) upper block (j, i), so that L stays intact.
+// (The block inverse by recursive doubling over the sub-blocks - T = L21 W11, W21 = -W22 T per level, at most 12 dependent
+// block products instead of 35 - was written and measured: 7.8 us against 8.2 us, each product is bound by its LDS round
+// trip and four dependent MFMAs whatever the chain length; not kept.)
 // Replaces, per 128 rows, two launches of the 64 x 64 kernel above and four single-tile GEMM launches (74 us ->
 // 49 us, phases: tools/probe/base_probe.hip): the serial chain of small launches is what bounds exact n <= 8192 and the replicated m x m
 // phase of the sparse models.  Contract as potrf_base_tile_kernel(..., wfull = 0): A's lower triangle <- L,
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
 #pragma unroll
         for (int q = 0; q < NBI * NBI / 512; ++q) {
             const int idx = tid + 512 * q, r = idx & (NBI - 1), c = idx >> 7;
-            v[q] = A[min(r, nb - 1) + (long)min(c, nb - 1) * lda];
+            v[q] = (c <= r) ? A[min(r, nb - 1) + (long)min(c, nb - 1) * lda] : 0.0;   // lower triangle only (masked, no wait between)
         }
 #pragma unroll
         for (int q = 0; q < NBI * NBI / 512; ++q) {
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
         double v = 0.0;
         if (br == bc) v = Wd[br][(r & 15) + (c & 15) * LDW];                               // zero above its diagonal
         else if (br > bc) v = S[(16 * bc + (r & 15)) + (16 * br + (c & 15)) * LDI];
-        if (r < nb) W[r + (long)c * ldw] = v;
+        if (r < nb && r >= c) W[r + (long)c * ldw] = v;   // W is zero above the diagonal on entry (contract of gpx_potrf_inv)
     }
     BASE_STAMP(5);
 }

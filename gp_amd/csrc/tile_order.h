@@ -2,6 +2,7 @@
 // sizes the launch.  Plain C++ on purpose: the kernel and gemm_impl use it, and tests/cpp/tile_order_check.cpp
 // enumerates every block of many launch plans on the CPU to check that each tile is computed exactly once.
 #pragma once
+#include <cstdlib>
 #include <cmath>
 #include "gemm_flags.h"
 
@@ -162,7 +163,8 @@ inline TilePlan plan_tiles(long M, long N, int flags, int splitk, bool has_kscal
         // a 64x64 tile is bound by the matrix pipe of the ONE CU it runs on (0.43 us per 16-deep K step): products
         // with at most 64 such tiles (the chains below 1024 rows) take 32x32 tiles, four times the CUs per product
         const long t64 = ((M + 63) / 64) * ((N + 63) / 64) / ((flags & GEMM_LOWER) ? 2 : 1);
-        if (bt == 64 && t64 * (splitk > 1 ? splitk : 1) <= 64 && !(flags & GEMM_NO_TILE32)) bt = 32;
+        static const long t32max = [] { const char* e = getenv("GPX_TILE32_MAX"); return e ? atol(e) : 64L; }();
+        if (bt == 64 && t64 * (splitk > 1 ? splitk : 1) <= t32max && !(flags & GEMM_NO_TILE32)) bt = 32;
     }
     if (flags & GEMM_TILE64) bt = 64;
     if (flags & GEMM_TILE128) bt = 128;
