@@ -58,6 +58,30 @@ struct Cfg {
 
 __device__ __forceinline__ v4d mfma(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
+// exp(x) for x <= 0 (the kernel's -r2/2): k = rint(x log2 e), r = x - k ln 2 in two pieces, degree-12 Taylor polynomial on
+// |r| <= 0.347 (truncation 1.7e-16 relative), ldexp.  No overflow / NaN branches: the argument is clamped at -800, where the
+// result is 0 as it is for the library exp (the library version spends 6 compare / select operations per value on them).
+__device__ __forceinline__ double exp_nonpos(double x) {
+    x = fmax(x, -800.0);
+    const double k = __builtin_rint(x * 1.4426950408889634);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;           // 1/12!
+    p = fma(p, r, 2.50521083854417187751e-08);       // 1/11!
+    p = fma(p, r, 2.75573192239858906526e-07);       // 1/10!
+    p = fma(p, r, 2.75573192239858906526e-06);       // 1/9!
+    p = fma(p, r, 2.48015873015873015873e-05);       // 1/8!
+    p = fma(p, r, 1.98412698412698412698e-04);       // 1/7!
+    p = fma(p, r, 1.38888888888888888889e-03);       // 1/6!
+    p = fma(p, r, 8.33333333333333333333e-03);       // 1/5!
+    p = fma(p, r, 4.16666666666666666667e-02);       // 1/4!
+    p = fma(p, r, 1.66666666666666666667e-01);       // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+
 // sum over the 16 lanes of a DPP row, every lane ends with the same bits (ds_bpermute shuffles would put
 // four dependent LDS round trips per tile on the critical path of a wave that has one partner to hide them)
 template <int CTRL>
@@ -123,8 +147,8 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_kernel(const MfmaPairArgs g) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long b = b0 + 16 * bt + 4 * r + l4;
-                const double k0 = g.sf2 * exp(-0.5 * fmax(D0[r], 0.0));
-                const double k1 = g.sf2 * exp(-0.5 * fmax(D1[r], 0.0));
+                const double k0 = g.sf2 * exp_nonpos(-0.5 * fmax(D0[r], 0.0));
+                const double k1 = g.sf2 * exp_nonpos(-0.5 * fmax(D1[r], 0.0));
                 double* o = g.out + a0 + b * g.ldo;
                 if (full) {
                     *reinterpret_cast<v2d*>(o) = (v2d){k0, k1};
@@ -269,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void trace_mfma_kernel(const MfmaPairArgs g
                         if (HAS_M2) w = fma(c2a[s], w2[r][s], w);
                         w = fma(ua[s], vb, w);
                         if (!bin) w = 0.0;
-                        q[s][r] = w * (g.sf2 * exp(-0.5 * fmax(D[s][r], 0.0)));
+                        q[s][r] = w * (g.sf2 * exp_nonpos(-0.5 * fmax(D[s][r], 0.0)));
                         cs += q[s][r];
                     }
                     // column sum over this wave's rows
@@ -353,6 +377,7 @@ __device__ __forceinline__ void dma_tile(const MfmaPairArgs& g, int b0, double* 
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int ldua = (int)g.ldua;                        // <= CACC_MAX: every offset below fits 32 bits
+    asm volatile("" : "+s"(wv));                         // the 15 row offsets are recomputed per tile (scalar unit), not kept in SGPRs that spill
     const char* pU = reinterpret_cast<const char*>(g.Ua + b0) + lane * 4;
     const char* pT = reinterpret_cast<const char*>(g.UaT + b0 * C::N2) + lane * 4;
 #pragma unroll
@@ -393,23 +418,26 @@ __global__ __launch_bounds__(512) void trace_mfma8_kernel(const MfmaPairArgs g) 
     const int nmine = (int)blockIdx.x < g.nblk ? (g.nblk - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int m = (int)g.m;
     // weights of tile tl of row block blk: this lane's 8 (b = b0 + 4 i + l4, a)
+    // uniform 64-bit base (scalar registers, advanced per tile by the scalar unit) + ONE loop-invariant 32-bit lane offset
+    const unsigned wo1 = (unsigned)(16 * wv + l15) + (unsigned)l4 * (unsigned)g.ldm1;   // 3 ldm1 + 127 < 2^32 for any matrix that fits the device
+    const unsigned wo2 = HAS_M2 ? (unsigned)(16 * wv + l15) + (unsigned)l4 * (unsigned)g.ldm2 : 0u;
     auto load_w = [&](int blk, int tl, double (&w1)[TB / 4], double (&w2)[TB / 4]) {
         const int b0 = tl * TB;
         const long a = (long)blk * RB + 16 * wv + l15;
-        const double* p1 = g.M1 + a + (long)(b0 + l4) * g.ldm1;
-        const double* p2 = HAS_M2 ? g.M2 + a + (long)(b0 + l4) * g.ldm2 : nullptr;
+        const double* s1 = g.M1 + (long)blk * RB + (long)b0 * g.ldm1;   // wave-uniform
+        const double* s2 = HAS_M2 ? g.M2 + (long)blk * RB + (long)b0 * g.ldm2 : nullptr;
         if ((long)blk * RB + RB <= g.n && b0 + TB <= m) {   // wave-uniform: the interior takes no per-load guard
 #pragma unroll
             for (int i = 0; i < TB / 4; ++i) {
-                w1[i] = p1[(long)(4 * i) * g.ldm1];
-                w2[i] = HAS_M2 ? p2[(long)(4 * i) * g.ldm2] : 0.0;
+                w1[i] = (s1 + (long)(4 * i) * g.ldm1)[wo1];
+                w2[i] = HAS_M2 ? (s2 + (long)(4 * i) * g.ldm2)[wo2] : 0.0;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < TB / 4; ++i) {
                 const bool in = b0 + 4 * i + l4 < m && a < g.n;
-                w1[i] = in ? p1[(long)(4 * i) * g.ldm1] : 0.0;
-                w2[i] = (HAS_M2 && in) ? p2[(long)(4 * i) * g.ldm2] : 0.0;
+                w1[i] = in ? (s1 + (long)(4 * i) * g.ldm1)[wo1] : 0.0;
+                w2[i] = (HAS_M2 && in) ? (s2 + (long)(4 * i) * g.ldm2)[wo2] : 0.0;
             }
         }
     };
@@ -473,7 +501,7 @@ __global__ __launch_bounds__(512) void trace_mfma8_kernel(const MfmaPairArgs g) 
                 if (HAS_M2) w = fma(c2a, wc2[4 * bt + r], w);
                 w = fma(ua, sv[st][bl], w);
                 if (b0 + bl >= m) w = 0.0;   // beyond m the operands are zero, K = sf2 there: the weight must vanish
-                q[r] = w * (g.sf2 * exp(-0.5 * fmax(Dg[r], 0.0)));
+                q[r] = w * (g.sf2 * exp_nonpos(-0.5 * fmax(Dg[r], 0.0)));
                 csum[st][wv][bl] = row16_sum(q[r]);   // the 16 lanes of a row hold the same sum: same value, same address
             }
         };
