@@ -1,5 +1,5 @@
 // gemm_shape_probe.hip — which of (tile count, K length, column stride, footprint) costs the fp64 GEMM its
-// last 6 % at n = 32768?  args: groups of "M N K ld [akc bkc flags]" separated by commas, e.g.
+// last 6 % at n = 32768?  args: groups of "M N K ld [akc bkc flags splitk_work_slabs]" separated by commas, e.g.
 //   gemm_shape_probe 16384 16384 16384 16400 , 16384 16384 16384 32784
 // build: as gemm_cached_probe.hip
 #include <cstdio>
@@ -47,10 +47,17 @@ int main(int argc, char** argv) {
         const int akc = c.size() > 4 ? (int)c[4] : 0, bkc = c.size() > 5 ? (int)c[5] : 0, flags = c.size() > 6 ? (int)c[6] : 0;
         const double fl = 2.0 * M * N * K;
         const int reps = fl < 2e13 ? 6 : 2;
-        gpx_gemm(st, akc, bkc, M, N, K, 1.0, A, ld, B, ld, 0.0, C, M, flags);
+        const long slabs = c.size() > 7 ? c[7] : 0;   // > 0: split-K with a workspace of that many M x N slabs
+        double* work = nullptr;
+        if (slabs > 0 && hipMalloc(&work, slabs * M * N * 8)) return 1;
+        auto run = [&]() {
+            if (slabs > 0) gpx_gemm_splitk(st, akc, bkc, M, N, K, 1.0, A, ld, B, ld, 0.0, C, M, flags, work, slabs * M * N);
+            else gpx_gemm(st, akc, bkc, M, N, K, 1.0, A, ld, B, ld, 0.0, C, M, flags);
+        };
+        run();
         (void)hipStreamSynchronize(st);
         (void)hipEventRecord(e0, st);
-        for (int i = 0; i < reps; ++i) gpx_gemm(st, akc, bkc, M, N, K, 1.0, A, ld, B, ld, 0.0, C, M, flags);
+        for (int i = 0; i < reps; ++i) run();
         (void)hipEventRecord(e1, st);
         (void)hipEventSynchronize(e1);
         float ms = 0;
