@@ -18,6 +18,22 @@ __global__ __launch_bounds__(256) void gemv_n_kernel(long M, long K, double alph
     if (i < M) {
         const double* a = A + i;
         long k = w;
+        // eight loads in flight per lane first: the long rows of a triangular factor are bound by load latency
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        for (; k + 28 < Kf; k += 32) {
+            s0 = fma(a[k * lda], x[k], s0);
+            s1 = fma(a[(k + 4) * lda], x[k + 4], s1);
+            s2 = fma(a[(k + 8) * lda], x[k + 8], s2);
+            s3 = fma(a[(k + 12) * lda], x[k + 12], s3);
+            t0 = fma(a[(k + 16) * lda], x[k + 16], t0);
+            t1 = fma(a[(k + 20) * lda], x[k + 20], t1);
+            t2 = fma(a[(k + 24) * lda], x[k + 24], t2);
+            t3 = fma(a[(k + 28) * lda], x[k + 28], t3);
+        }
+        s0 += t0;
+        s1 += t1;
+        s2 += t2;
+        s3 += t3;
         for (; k + 12 < Kf; k += 16) {
             s0 = fma(a[k * lda], x[k], s0);
             s1 = fma(a[(k + 4) * lda], x[k + 4], s1);
