@@ -252,7 +252,7 @@ struct Sparse {
         if ((rc = c->T.ensure(gpx_trtri_scratch(m) > 64 * mm ? gpx_trtri_scratch(m) : 64 * mm))) return rc;  // trtri scratch / split-K slabs
         for (int i = 0; i < 8; ++i)
             if ((rc = c->vn[i].ensure(n)) || (rc = c->vm[i].ensure(m + 80))) return rc;  // + 64: direct-to-LDS loads read whole 32-entry tiles
-        if ((rc = c->red.ensure(m * m + m + GPX_MAX_DIM + 64))) return rc;
+        if ((rc = c->red.ensure(m * m + m + GPX_MAX_DIM + 96))) return rc;
         if ((rc = c->r.ensure(n))) return rc;
         if ((rc = c->pred_tmp.ensure((long)PW * (nblk(n) > nblk(m * m) ? nblk(n) : nblk(m * m)) + 64))) return rc;
         return GPX_OK;
@@ -367,9 +367,12 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     const int d = s.d, nh = h.nk + 2;
     hipStream_t st = c->st;  // main stream; phase 2 switches to the side stream
     const bool fitc = model == GPX_MODEL_FITC;
-    double* red = c->red.p;          // [m*m | m | tail]
-    double* redF = red + m * m;
-    double* redT = redF + m;
+    // reduction buffer [F (m, padded to 16) | S (m*m) | tail]: all-reduce #1 takes F, S and the first tail entries,
+    // all-reduce #2 of FITC takes S and the tail only (F is not reduced a second time)
+    const long mp = (m + 15) / 16 * 16;
+    double* redF = c->red.p;
+    double* red = redF + mp;         // the m x m slot
+    double* redT = red + m * m;
     double* a_vec = c->vm[0].p;
     double* g = c->vn[0].p;   // 1/Gamma
     double* p = c->vn[1].p;   // r/Gamma
@@ -381,6 +384,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     // ---- phase 1 ------------------------------------------------------------------------------
     if ((rc = s.kernels(jitter, true, true))) return rc;  // Lu diag + Winv_u = Lu^-1
     HIP_TRY(hipMemsetAsync(redT, 0, 16 * sizeof(double), st));
+    if (mp > m) HIP_TRY(hipMemsetAsync(redF + m, 0, (mp - m) * sizeof(double), st));   // the padding travels with all-reduce #1
     if (fitc) {
         // V = Kxu Lu^-T (FITC.cpp:213-215 via the factor: diag(Kxu Kuu^-1 Kux) = rowsum(V o V))
         if ((rc = s.v_and_gamma(c->Winv_u.p, c->r.p, h.sn2, h.sf2, g, p))) return rc;
@@ -403,7 +407,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         // all-reduce and the (narrow) factor chain of A run beside it
         if ((rc = gpx_gemm(st, 0, 1, n, m, m, 1.0, c->V.p, ldn, c->Winv_u.p, ldm, 0.0, c->Bm.p, ldn, GEMM_KLO_N))) return rc;
     }
-    if ((rc = s.allreduce(red, m * m + m + 16, c->st2, c->ev[0]))) return rc;
+    if ((rc = s.allreduce(redF, mp + m * m + 16, c->st2, c->ev[0]))) return rc;
 
     // ---- phase 2 (side stream) ------------------------------------------------------------------
     // A = sn2*Kuu + S (FITC.cpp:217, VFE.cpp:174), factor, a = A^-1 F
@@ -489,7 +493,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Bm.p, ldn, c->Bm.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
                                   wv)))
             return rc;
-        if ((rc = s.allreduce(red, m * m + m + GPX_MAX_DIM + 32, st))) return rc;
+        if ((rc = s.allreduce(red, m * m + GPX_MAX_DIM + 32, st))) return rc;
         hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, red, m);
         // W_uu = sn2 A^-1 - Kuu^-1 + a a^T + B^T diag(w) B / sn2
         hipLaunchKernelGGL(mm_combine_full_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, h.sn2, c->A_inv.p, ldm, -1.0,
@@ -569,8 +573,9 @@ int gpx_sparse_prepare(gpx_ctx* c, int model, int cov, const double* hyp, double
     const long n = s.n, m = s.m, ldn = s.ldn, ldm = s.ldm;
     hipStream_t st = c->st;
     const bool fitc = model == GPX_MODEL_FITC;
-    double* red = c->red.p;
-    double* redF = red + m * m;
+    const long mp = (m + 15) / 16 * 16;   // [F | S] as in gpx_sparse_nll_grad
+    double* redF = c->red.p;
+    double* red = redF + mp;
     double* a_vec = c->vm[0].p;
     double cum = 0.0;  // VFE: jitter accumulated on Kuu's diagonal
     for (int iter = 0; iter < 200; ++iter) {
@@ -597,7 +602,8 @@ int gpx_sparse_prepare(gpx_ctx* c, int model, int cov, const double* hyp, double
                                       c->T.cap)))
                 return rc;
         }
-        if ((rc = s.allreduce(red, m * m + m, st))) return rc;
+        if (mp > m) HIP_TRY(hipMemsetAsync(redF + m, 0, (mp - m) * sizeof(double), st));
+        if ((rc = s.allreduce(redF, mp + m * m, st))) return rc;
         if (fitc) {
             // A = sn2*Kuu(no jitter) + S, and A + jitter*I inside the retry loop (FITC.cpp:180,195-196)
             const double dadd = -h.sn2 * kuu_add + (first ? 0.0 : *jitter);
