@@ -199,3 +199,36 @@ def test_sparse_golden_fixture_and_failure(gpx):
         st = oracle.SparseState(model, 0, g["X"], g["y"], Ud, 1e-10, g["ard_hyp"])
         assert j2 > 1e-10 and 0.2 <= j2 / st.jitter <= 5.0   # pivot rounding may shift the loop by a step
     ctx.close()
+
+
+@pytest.mark.parametrize("model", ["fitc", "vfe"])
+@pytest.mark.parametrize("d", [31, 34, 38, 42, 46, 50, 54, 58, 62])
+def test_deep_contractions_every_kernel_instantiation(gpx, model, d):
+    """d = 31..62: every depth KK = 9..16 of the matrix-core pairwise kernels (VFE: the 8-wave direct-to-LDS trace
+    kernel, FITC: the 4-wave kernel with two weight matrices, both: cov_mfma_kernel<KK>) against the oracle and
+    against the vector-unit kernels of the same library (GPX_NO_MFMA_PAIRWISE=1), ragged n and m."""
+    n, m = 777, 70
+    X, y, hyp, Xs, U = problem(0, n, d, m)
+    hyp[:d] += 0.5 * np.log(d / 5.0)     # lengthscales grow with sqrt(d): distances stay O(1), K does not underflow
+    M = gpx.MODEL_FITC if model == "fitc" else gpx.MODEL_VFE
+    res = {}
+    for tag, env in (("mfma", None), ("valu", "1")):
+        if env is None:
+            os.environ.pop("GPX_NO_MFMA_PAIRWISE", None)
+        else:
+            os.environ["GPX_NO_MFMA_PAIRWISE"] = env
+        try:
+            ctx = gpx.Context()
+        finally:
+            os.environ.pop("GPX_NO_MFMA_PAIRWISE", None)
+        ctx.set_data(X, y)
+        ctx.set_inducing(U)
+        res[tag] = ctx.nll_grad(M, 0, hyp, jitter=1e-6)
+        ctx.close()
+    fo = oracle.fitc_nll if model == "fitc" else oracle.vfe_nll
+    nll_o, g_o = fo(0, X, y, U, 1e-6, hyp)
+    for tag in ("mfma", "valu"):
+        nll, g = res[tag]
+        assert abs(nll - nll_o) <= 1e-9 * abs(nll_o), (tag, d)
+        assert rel(g, g_o) <= 1e-7, (tag, d, rel(g, g_o))
+    assert rel(res["mfma"][1], res["valu"][1]) <= 1e-8
