@@ -441,6 +441,8 @@ __global__ __launch_bounds__(512) void trace_mfma8_kernel(const MfmaPairArgs g) 
             }
         }
     };
+    // (Three weight register sets in rotation, i.e. a tile's weights requested TWO tiles ahead with the tile body unrolled
+    // three times, were measured: slower - FITC 5.13 -> 5.39 ms, VFE 51.5 -> 58.4 ms at 255 VGPRs with spills; not kept.)
     double wc1[TB / 4], wc2[TB / 4], wn1[TB / 4], wn2[TB / 4];
     double xf[KK];
     double c1a = 1.0, c2a = 1.0, ua = 0.0;
