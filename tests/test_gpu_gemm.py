@@ -186,3 +186,30 @@ def test_gemm_rowdot_epilogue_ragged_shapes(shape, with_e):
         ref = A @ Bt.T
         assert np.max(np.abs(C - ref)) <= 1e-12 * np.max(np.abs(ref)) * K
         assert np.max(np.abs(R1.sum(axis=0) - np.sum(ref * ref, axis=1))) <= 1e-11 * np.max(np.sum(ref * ref, axis=1)) * K
+
+
+@pytest.mark.parametrize("layout", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_32_tiles_for_products_of_few_tiles(layout):
+    """Products of at most 64 tiles of 64x64 take 32x32 tiles (gemm_kernel<1,1,..>, the chains below 1024 rows): every
+    operand layout, full, LOWER and triangular K ranges, against NumPy and against the 64x64-tile launch of the same
+    product (GEMM_NO_TILE32)."""
+    lib = _lib()
+    a_kc, b_kc = layout
+    rng = np.random.default_rng(5)
+    for (M, N, K) in [(512, 512, 512), (200, 130, 77), (96, 96, 300)]:
+        A, B = rng.standard_normal((M, K)), rng.standard_normal((N, K))
+        C0 = rng.standard_normal((M, N))
+        ref = 0.5 * A @ B.T - 2.0 * C0
+        C = lib.dgemm(A, B, C0, a_kc=a_kc, b_kc=b_kc, alpha=0.5, beta=-2.0)
+        C64 = lib.dgemm(A, B, C0, a_kc=a_kc, b_kc=b_kc, alpha=0.5, beta=-2.0, flags=lib.GEMM_NO_TILE32)
+        tol = 1e-13 * K * max(1.0, np.max(np.abs(ref)))
+        assert np.max(np.abs(C - ref)) <= tol and np.max(np.abs(C64 - ref)) <= tol
+    n = 384
+    D = rng.standard_normal((n, n))
+    L = np.tril(rng.standard_normal((n, n)))
+    C = lib.dgemm(D, D, flags=lib.GEMM_LOWER)
+    assert np.max(np.abs(np.tril(C) - np.tril(D @ D.T))) <= 1e-11
+    C = lib.dgemm(D, L, flags=lib.GEMM_KHI_N)            # B(n,k) = L[n,k], zero for k > n
+    assert np.max(np.abs(C - D @ L.T)) <= 1e-11
+    C = lib.dgemm(L, D.T.copy(), flags=lib.GEMM_KHI_M | lib.GEMM_HEAVY_LAST, b_kc=True)   # A(m,k) = L[m,k], zero for k > m
+    assert np.max(np.abs(C - L @ D)) <= 1e-11
