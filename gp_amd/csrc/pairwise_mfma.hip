@@ -16,6 +16,8 @@
 //    block.  The column sums Q^T 1 are a 16-lane reduction per tile.  3 d vector operations per pair become
 //    2 (dk + 16 ceil((d+1)/16)) matrix flops per pair.
 //
+// Two trace kernels: trace_mfma_kernel (below) and, for d > 30 with one weight matrix (the VFE trace),
+// trace_mfma8_kernel: one 8-wave workgroup per CU, direct-to-LDS staging one tile ahead, one barrier per tile.
 // Workgroup = 4 waves = 128 training rows (32 per wave: two interleaved 16-row MFMA tiles, so that a lane's two
 // rows are adjacent in memory and every weight load is 16 B); inducing points go through LDS 64 at a time in two
 // images (row-major for the first product, transposed for the second), both conflict-free for their fragment
@@ -688,15 +690,20 @@ __global__ void trace_mfma_finish_kernel(const double* __restrict__ spart, int n
 
 #define GPX_KK8_CASE(M2, K, grid, st, args) \
     case K: hipLaunchKernelGGL((trace_mfma8_kernel<K, M2>), dim3(grid), dim3(512), 0, st, args); break;
-#define GPX_KK8_SWITCH(M2, kk, grid, st, args)                                                                   \
+#define GPX_KK8_SWITCH_SHALLOW(M2, kk, grid, st, args)                                                           \
     switch (kk) {                                                                                                \
         GPX_KK8_CASE(M2, 1, grid, st, args) GPX_KK8_CASE(M2, 2, grid, st, args) GPX_KK8_CASE(M2, 3, grid, st, args) \
         GPX_KK8_CASE(M2, 4, grid, st, args) GPX_KK8_CASE(M2, 5, grid, st, args) GPX_KK8_CASE(M2, 6, grid, st, args) \
-        GPX_KK8_CASE(M2, 7, grid, st, args) GPX_KK8_CASE(M2, 8, grid, st, args)                                    \
-        GPX_KK8_CASE(M2, 9, grid, st, args) GPX_KK8_CASE(M2, 10, grid, st, args) GPX_KK8_CASE(M2, 11, grid, st, args) \
-        GPX_KK8_CASE(M2, 12, grid, st, args) GPX_KK8_CASE(M2, 13, grid, st, args) GPX_KK8_CASE(M2, 14, grid, st, args) \
-        GPX_KK8_CASE(M2, 15, grid, st, args)                                                                      \
-        default: hipLaunchKernelGGL((trace_mfma8_kernel<16, M2>), dim3(grid), dim3(512), 0, st, args); break;     \
+        GPX_KK8_CASE(M2, 7, grid, st, args)                                                                        \
+        default: hipLaunchKernelGGL((trace_mfma8_kernel<8, M2>), dim3(grid), dim3(512), 0, st, args); break;      \
+    }
+#define GPX_KK8_SWITCH_DEEP(kk, grid, st, args)   /* one weight matrix only: with two the registers spill */       \
+    switch (kk) {                                                                                                \
+        GPX_KK8_CASE(false, 9, grid, st, args) GPX_KK8_CASE(false, 10, grid, st, args)                             \
+        GPX_KK8_CASE(false, 11, grid, st, args) GPX_KK8_CASE(false, 12, grid, st, args)                            \
+        GPX_KK8_CASE(false, 13, grid, st, args) GPX_KK8_CASE(false, 14, grid, st, args)                            \
+        GPX_KK8_CASE(false, 15, grid, st, args)                                                                    \
+        default: hipLaunchKernelGGL((trace_mfma8_kernel<16, false>), dim3(grid), dim3(512), 0, st, args); break;  \
     }
 
 inline int kk_of(int d) { return (d + 2 + 3) / 4; }
@@ -781,10 +788,12 @@ int gpx_mfma_pair_trace(hipStream_t st, const double* Xa, long n, const double* 
     g.nblk = (int)nblk;
     HIP_TRY(hipMemsetAsync(cpart, 0, (size_t)grid * g.ldua * sizeof(double), st));
     const long slot = gpx_pair_prof_open(st, 1, 8.0 * (double)n * (double)m * (w.M2 ? 2.0 : 1.0));
-    if (trace_wide(d, m, two) && two) {
-        GPX_KK8_SWITCH(true, kk_of(d), (unsigned)grid, st, g);
+    if (trace_wide(d, m, two) && kk_of(d) > 8) {
+        GPX_KK8_SWITCH_DEEP(kk_of(d), (unsigned)grid, st, g);
+    } else if (trace_wide(d, m, two) && two) {
+        GPX_KK8_SWITCH_SHALLOW(true, kk_of(d), (unsigned)grid, st, g);
     } else if (trace_wide(d, m, two)) {
-        GPX_KK8_SWITCH(false, kk_of(d), (unsigned)grid, st, g);
+        GPX_KK8_SWITCH_SHALLOW(false, kk_of(d), (unsigned)grid, st, g);
     } else if (w.M2) {
         GPX_KK_SWITCH(GPX_TRACE_K2, kk_of(d), (unsigned)grid, st, g);
     } else {
