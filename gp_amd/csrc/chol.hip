@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256) void potrf_base_tile_kernel(double* __restrict
 //                             columns broadcast with v_readlane);  the panel below it is a forward substitution
 //                             X L_kk^T = S_:k with one row per thread (L_kk read as LDS broadcasts), so that no
 //                             inverse sits on the critical path;  the trailing update  S_ij -= L_ik L_jk^T  is one
-//                             4-MFMA chain per sub-block, spread over the 8 waves;  3 barriers per k.
+//                             4-MFMA chain per sub-block, with a look-ahead: block column k + 1 first (all 8 waves),
+//                             then wave 0 factors diagonal sub-block k + 1 WHILE waves 1..7 update the rest
+//                             (factor phase 29 us -> 25 us at nb = 128);  3 barriers per k.
 //   The inverses of the diagonal sub-blocks follow, all at once (one per wave, one column per lane).
 //   W = L^-1 by forward substitution per block column, W_ij = -W_ii sum_{k=j}^{i-1} L_ik W_kj, one block column
 //   per wave with no barrier at all: W_ij is stored in the (unused) upper block (j, i), so that L stays intact.
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void potrf_base_tile_kernel(double* __restrict
 // block products instead of 35 - was written and measured: 7.8 us against 8.2 us, each product is bound by its LDS round
 // trip and four dependent MFMAs whatever the chain length; not kept.)
 // Replaces, per 128 rows, two launches of the 64 x 64 kernel above and four single-tile GEMM launches (74 us ->
-// 49 us, phases: tools/probe/base_probe.hip): the serial chain of small launches is what bounds exact n <= 8192 and the replicated m x m
+// 43 us, phases: tools/probe/base_probe.hip): the serial chain of small launches is what bounds exact n <= 8192 and the replicated m x m
 // phase of the sparse models.  Contract as potrf_base_tile_kernel(..., wfull = 0): A's lower triangle <- L,
 // W (nb x nb) <- L^-1 with zeros above the diagonal, *info = 1 on a pivot <= 0 (Eigen::LLT NumericalIssue).
 constexpr int NBI = 128;       // rows of the base block
@@ -195,10 +197,8 @@ constexpr int LDW = 17;        // leading dimension of the 16 x 16 diagonal inve
 #ifdef GPX_BASE_TIMING             // tools/probe/base_probe.hip: 100 MHz time stamps of the kernel's phases
 __device__ long long g_base_t[64];
 #define BASE_STAMP(i) do { if (threadIdx.x == 0) g_base_t[i] = wall_clock64(); } while (0)
-#define BASE_ADD(i, t0) do { if (threadIdx.x == 0) g_base_t[i] += wall_clock64() - (t0); } while (0)
 #else
 #define BASE_STAMP(i) do { } while (0)
-#define BASE_ADD(i, t0) do { } while (0)
 #endif
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {   // lane: wave-uniform
@@ -217,10 +217,6 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, l4 = lane >> 4;
     const int nblk = (nb + 15) / 16, np = 16 * nblk;
     BASE_STAMP(0);
-#ifdef GPX_BASE_TIMING
-    if (threadIdx.x == 0) g_base_t[8] = g_base_t[9] = g_base_t[10] = g_base_t[11] = g_base_t[12] = g_base_t[13] = 0;
-    long long tph = 0;
-#endif
     {   // lower triangle, identity padding, zeros above: all loads of a thread in flight together (clamped addresses,
         // no divergent branches; a guarded loop pays one HBM round trip per element: 32 in a row)
         double v[NBI * NBI / 512];
@@ -236,53 +232,50 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
         }
     }
     bool bad = false;
+    auto chol = [&](int o) {   // wave 0 only
+        // ---- Cholesky of the 16 x 16 diagonal sub-block: lane i (and its three copies) holds row i
+        double r[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) r[c] = S[(o + l15) + (o + c) * LDI];
+        double tl = 0.0;   // 1 / l_jj of this lane's row
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double d = readlane_f64(r[j], j);
+            bad = bad || !(d > 0.0);
+            // 1/sqrt(d) on the critical path of the whole block: hardware estimate t0 (>= 26 bits), then ONE third-order
+            // step t0 (1 + e/2 + 3 e^2/8), e = 1 - d t0^2 (error ~ e^3: full precision, two dependent operations less
+            // than two Newton steps)
+            double t = __builtin_amdgcn_rsq(d);
+            const double er = fma(-d * t, t, 1.0);
+            t = fma(t * er, fma(0.375, er, 0.5), t);
+            if (l15 == j) tl = t;
+            const double lij = r[j] * t;                    // column j of L (lane j: sqrt(d))
+            r[j] = lij;
+#pragma unroll
+            for (int c = j + 1; c < 16; ++c) r[c] = fma(-lij, readlane_f64(lij, c), r[c]);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) S[(o + l15) + (o + c) * LDI] = (c <= l15) ? r[c] : 0.0;
+            invd[o + l15] = tl;
+        }
+    };
+    auto trail = [&](int o, int bi, int bj) {   // S_ij -= L_ik L_jk^T
+        v4d D;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) D[r] = S[(16 * bi + l4 + 4 * r) + (16 * bj + l15) * LDI];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            D = mfma16(-S[(16 * bi + l15) + (o + 4 * kk + l4) * LDI], S[(16 * bj + l15) + (o + 4 * kk + l4) * LDI], D);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(16 * bi + l4 + 4 * r) + (16 * bj + l15) * LDI] = D[r];
+    };
+    __syncthreads();
+    BASE_STAMP(1);
+    if (wv == 0) chol(0);
     for (int k = 0; k < nblk; ++k) {
         const int o = 16 * k;
-        __syncthreads();   // S_kk carries every update of the steps before
-#ifdef GPX_BASE_TIMING
-        if (k == 0) BASE_STAMP(1);
-        tph = wall_clock64();
-#endif
-        if (wv == 0) {
-            // ---- Cholesky of the 16 x 16 diagonal sub-block: lane i (and its three copies) holds row i
-            double r[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) r[c] = S[(o + l15) + (o + c) * LDI];
-            double tl = 0.0;   // 1 / l_jj of this lane's row
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double d = readlane_f64(r[j], j);
-                bad = bad || !(d > 0.0);
-                // 1/sqrt(d) on the critical path of the whole block: hardware estimate t0 (>= 26 bits), then ONE third-order
-                // step t0 (1 + e/2 + 3 e^2/8), e = 1 - d t0^2 (error ~ e^3: full precision, two dependent operations less
-                // than two Newton steps)
-                double t = __builtin_amdgcn_rsq(d);
-                const double er = fma(-d * t, t, 1.0);
-                t = fma(t * er, fma(0.375, er, 0.5), t);
-                if (l15 == j) tl = t;
-                const double lij = r[j] * t;                    // column j of L (lane j: sqrt(d))
-                r[j] = lij;
-#pragma unroll
-                for (int c = j + 1; c < 16; ++c) r[c] = fma(-lij, readlane_f64(lij, c), r[c]);
-            }
-#ifdef GPX_BASE_TIMING
-            BASE_ADD(11, tph);
-            long long tq = wall_clock64();
-#endif
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) S[(o + l15) + (o + c) * LDI] = (c <= l15) ? r[c] : 0.0;
-                invd[o + l15] = tl;
-            }
-#ifdef GPX_BASE_TIMING
-            BASE_ADD(12, tq);
-#endif
-        }
-        __syncthreads();
-#ifdef GPX_BASE_TIMING
-        BASE_ADD(8, tph);
-        tph = wall_clock64();
-#endif
+        __syncthreads();   // L_kk and 1 / l_jj are there, and so is every trailing update of the step before
         // ---- panel: X L_kk^T = S_:k by forward substitution, one row of the panel per thread (L_kk as LDS broadcasts):
         // no inverse of the diagonal sub-block on the critical path of the factorisation
         {
@@ -302,26 +295,20 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
             }
         }
         __syncthreads();
-#ifdef GPX_BASE_TIMING
-        BASE_ADD(9, tph);
-        tph = wall_clock64();
-#endif
-        // ---- trailing update: S_ij -= L_ik L_jk^T for k < j <= i
+        // ---- trailing update with a look-ahead: first the block column k + 1 (all the next diagonal factorisation
+        // and the next panel need), then wave 0 factors the next diagonal sub-block WHILE waves 1..7 update the rest
         const int t = nblk - k - 1;
-        for (int p = wv; p < t * (t + 1) / 2; p += 8) {
-            int i = 0, rem = p;   // p -> (i, j), row-major over the lower triangle of the t x t trailing blocks
-            while (rem > i) rem -= ++i;
-            const int bi = k + 1 + i, bj = k + 1 + rem;
-            v4d D;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) D[r] = S[(16 * bi + l4 + 4 * r) + (16 * bj + l15) * LDI];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                D = mfma16(-S[(16 * bi + l15) + (o + 4 * kk + l4) * LDI], S[(16 * bj + l15) + (o + 4 * kk + l4) * LDI], D);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) S[(16 * bi + l4 + 4 * r) + (16 * bj + l15) * LDI] = D[r];
+        for (int q = wv; q < t; q += 8) trail(o, k + 1 + q, k + 1);
+        __syncthreads();
+        if (wv == 0) {
+            if (t > 0) chol(o + 16);
+        } else {
+            for (int p = wv - 1; p < t * (t - 1) / 2; p += 7) {
+                int i = 0, rem = p;   // p -> (i, rem), row-major over the lower triangle of the (t - 1) x (t - 1) blocks right of column k + 1
+                while (rem > i) rem -= ++i;
+                trail(o, k + 2 + i, k + 2 + rem);
+            }
         }
-        BASE_ADD(10, tph);
     }
     __syncthreads();
     BASE_STAMP(2);
