@@ -53,7 +53,7 @@ struct gpx_ctx {
     DevBuf vn[8], vm[8], red;
     // matrix-core pairwise path (pairwise_mfma.hip): centred, augmented operands and its partial sums
     DevBuf Xa, Ua, UaT, cen, cpart, spart, cvec;
-    DevBuf rowp1, rowp2;  // FITC: per-64-column partial row sums written by the GEMM row-dot epilogue [ceil(m/64)][ldn]
+    DevBuf rowp1, rowp2;  // FITC: per-64-column partial row sums written by the GEMM row-dot epilogue [2 ceil(m/128)][ldn]
     bool mfma_pairwise = true;   // GPX_NO_MFMA_PAIRWISE=1 keeps the vector-unit kernels (A/B runs, fallback tests)
     // all-reduce hook for row-sharded FITC/VFE
     gpx_allreduce_fn allreduce = nullptr;                 // host-synchronous flavour

@@ -37,7 +37,7 @@ struct GemmArgs : TileOrder {
     long slab;     // doubles between split-K slabs
     int fastA, fastB;  // base pointer and ld allow 16-B vector loads
     const double* kscale;  // optional: op(A)(m,k) is multiplied by kscale[k] on its way into the MFMAs (K-contiguous A only)
-    // optional row-dot epilogue (128-tiles, beta == 0, no split-K): per 64-column part p of the output
+    // optional row-dot epilogue (128-tiles, beta == 0, no split-K): per part p of the output (64 columns: those one wave of the tile owns, see sub16)
     //   R1[p*ldr + m] = sum_{n in part} C(m,n) * E(m,n)   (E == nullptr: E = C, i.e. row sums of squares)
     //   R2[p*ldr + m] = sum_{n in part} E(m,n) * evec[n]   (when E and evec are given)
     // so that the row statistics of a tall-skinny product do not cost a pass of their own over it
@@ -46,10 +46,18 @@ struct GemmArgs : TileOrder {
     double* R1; double* R2; long ldr;
 };
 
-// the row-dot epilogue of one wave: acc[j][i][r] = C(m0 + wm + 16 i + l15, n0 + wn + 16 j + l4 + 4 r) / alpha
+// Offset of a wave's i-th 16-row (16-column) group inside the block tile, relative to the wave's base.  With four groups per
+// wave (128-tiles) the ownership is INTERLEAVED: groups 0, 1 lie in the first 64 rows of the tile and groups 2, 3 in the
+// second 64 (wave base 32 (wave & 1)), so that a K range that only concerns one half of the tile (triangular operands
+// cut at 64) halves the work of EVERY wave alike.
+template <int T>
+__device__ __forceinline__ constexpr int sub16(int i) { return T == 4 ? (i & 1) * 16 + (i >> 1) * 64 : 16 * i; }
+
+// the row-dot epilogue of one wave: acc[j][i][r] = C(mb + sub16(i) + l15, nb + sub16(j) + l4 + 4 r) / alpha; part: the wave's
+// slot among the 2 * ceil(N / 128) row-dot parts
 // RD == 1: E = C (row sums of squares, R1 only); RD == 2: E, evec, R1 and R2 all given
 template <int TM, int TN, bool FULL, int RD>
-__device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const v4d (&acc)[TN][TM], int mb, int nb, int l15, int l4) {
+__device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const v4d (&acc)[TN][TM], int mb, int nb, int part, int l15, int l4) {
     double s1[TM], s2[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) s1[i] = s2[i] = 0.0;
@@ -61,22 +69,23 @@ __device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const v4d (&a
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool nin = FULL || nb + 16 * j + l4 + 4 * r < g.N;
+            const bool nin = FULL || nb + sub16<TN>(j) + l4 + 4 * r < g.N;
             if (RD == 2) {
                 double e[TM], ev;
                 if (FULL) {
-                    ev = vp[16 * j + 4 * r];
+                    if (TN == 4 && j == 2 && r == 0) ep += 8 * estep;   // groups 2, 3: the second 64 columns of the tile
+                    ev = vp[sub16<TN>(j) + 4 * r];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) e[i] = ep[16 * i];
+                    for (int i = 0; i < TM; ++i) e[i] = ep[sub16<TM>(i)];
                     ep += estep;
                 } else {   // edge tiles: clamped addresses and 0/1 masks instead of guarded loads (no divergent branches)
-                    const int n = nb + 16 * j + l4 + 4 * r;
+                    const int n = nb + sub16<TN>(j) + l4 + 4 * r;
                     const double nmask = n < g.N ? 1.0 : 0.0;
                     const double* col = g.E + (long)min(n, g.N - 1) * g.lde;
                     ev = g.evec[min(n, g.N - 1)] * nmask;
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
-                        const int m = mb + 16 * i + l15;
+                        const int m = mb + sub16<TM>(i) + l15;
                         e[i] = col[min(m, g.M - 1)] * (m < g.M ? nmask : 0.0);
                     }
                 }
@@ -94,7 +103,7 @@ __device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const v4d (&a
                 }
             }
         }
-    const long off = (long)(nb / (16 * TN)) * g.ldr;
+    const long off = (long)part * g.ldr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         double a = s1[i], b = s2[i];
@@ -104,7 +113,7 @@ __device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const v4d (&a
             b += __shfl_xor(b, 16, 64);
             b += __shfl_xor(b, 32, 64);
         }
-        const int m = mb + 16 * i + l15;
+        const int m = mb + sub16<TM>(i) + l15;
         if (l4 == 0 && (FULL || m < g.M)) {
             g.R1[off + m] = a;
             if (RD == 2) g.R2[off + m] = b;
@@ -116,7 +125,7 @@ __device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const v4d (&a
 // are stored while they are in flight, then the two row dots are formed (separate store and dot passes leave the
 // matrix pipe idle for 64 load round trips in 8 batches per tile: Cu GEMM 29.8 -> 32.2 ms at n = 2^20)
 template <int TM, int TN>
-__device__ __forceinline__ void store_rowdot_full(const GemmArgs& g, const v4d (&acc)[TN][TM], double* Cb, int mb, int nb, int l15, int l4) {
+__device__ __forceinline__ void store_rowdot_full(const GemmArgs& g, const v4d (&acc)[TN][TM], double* Cb, int mb, int nb, int part, int l15, int l4) {
     double s1[TM], s2[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) s1[i] = s2[i] = 0.0;
@@ -127,17 +136,21 @@ __device__ __forceinline__ void store_rowdot_full(const GemmArgs& g, const v4d (
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         double e[4][TM], ev[4];
+        if (TN == 4 && j == 2) {   // groups 2, 3: the second 64 columns of the tile
+            ep += 8 * estep;
+            cp += 8 * cstep;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            ev[r] = vp[16 * j + 4 * r];
+            ev[r] = vp[sub16<TN>(j) + 4 * r];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) e[r][i] = ep[16 * i];
+            for (int i = 0; i < TM; ++i) e[r][i] = ep[sub16<TM>(i)];
             ep += estep;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) cp[16 * i] = g.alpha * acc[j][i][r];
+            for (int i = 0; i < TM; ++i) cp[sub16<TM>(i)] = g.alpha * acc[j][i][r];
             cp += cstep;
         }
 #pragma unroll
@@ -149,7 +162,7 @@ __device__ __forceinline__ void store_rowdot_full(const GemmArgs& g, const v4d (
             }
         __builtin_amdgcn_sched_barrier(0);   // one group of E in flight at a time: all accumulators are live here
     }
-    const long off = (long)(nb / (16 * TN)) * g.ldr;
+    const long off = (long)part * g.ldr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         double a = s1[i], b = s2[i];
@@ -158,8 +171,8 @@ __device__ __forceinline__ void store_rowdot_full(const GemmArgs& g, const v4d (
         b += __shfl_xor(b, 16, 64);
         b += __shfl_xor(b, 32, 64);
         if (l4 == 0) {
-            g.R1[off + mb + 16 * i + l15] = a;
-            g.R2[off + mb + 16 * i + l15] = b;
+            g.R1[off + mb + sub16<TM>(i) + l15] = a;
+            g.R2[off + mb + sub16<TM>(i) + l15] = b;
         }
     }
 }
@@ -224,7 +237,7 @@ __device__ __forceinline__ double sfrag(const double* __restrict__ s, int row, i
     return KC ? s[row * (BK + 2) + k] : s[k * (BMN + 16) + row];
 }
 
-template <int TM, int TN, bool AKC, bool BKC, int RD = 0>
+template <int TM, int TN, bool AKC, bool BKC, int RD = 0, int SK = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     constexpr int NT = 256;
     constexpr int BM = 32 * TM, BN = 32 * TN;
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave & 1) * (16 * TM), wn = (wave >> 1) * (16 * TN);
+    const int wm = (wave & 1) * (TM == 4 ? 32 : 16 * TM), wn = (wave >> 1) * (TN == 4 ? 32 : 16 * TN);   // see sub16
     const int l15 = lane & 15, l4 = lane >> 4;
 
     v4d acc[TN][TM];
@@ -333,6 +346,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         const char* ps = reinterpret_cast<const char*>(g.kscale) + k00 * 8;
         const long ksd = down ? -(long)BK * 8 : (long)BK * 8;
         const unsigned soff = (unsigned)((lane & 31) * 4);
+        // Half-tile skipping (see sub16; SK != 0 instantiations, chosen by the host from the flags).  A K tile of a
+        // triangular operand that only concerns the first / second 64 columns of the tile (K ranges cut at 64 instead of 128:
+        // 1/18 of the flops of a 1024-wide triangular product) is left out by EVERY wave alike.  The K loop is cut into
+        // three consecutive loops, each with ONE compile-time shape of the multiply - half, full, half - and run-time trip
+        // counts (no branch inside a loop: branches between differently shaped multiplies, a switch or if-chain per K
+        // tile, cost the register allocator 300 - 1000 spilled registers and the FITC evaluation 113 -> 141 ms).
+        //   SK 1: GEMM_KHI_N, K tiles with k >= n0 + 64 multiply column groups 2, 3 only
+        //   SK 2: GEMM_KLO_N, K tiles with k <  n0 + 64 multiply column groups 0, 1 only
+        // Measured at n = 2^20, m = 1024: V 17.73 -> 17.27 ms, B 17.73 -> 17.44 ms (half of the 1/18: the half-shaped K
+        // tiles load as much as the full ones).  A third shape for the diagonal tiles of a LOWER product (all but rows
+        // 0-63 x columns 64-127) made the split-K Gram products SLOWER, 17.7 -> 18.6 ms: the diagonal tiles run ahead of the
+        // other tiles of their slab and fetch their operands from HBM a second time; not kept.
         auto run = [&](auto SC) {
             constexpr bool scaled = decltype(SC)::value;
             auto issue = [&](int stage) {
@@ -352,52 +377,73 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 pa += ka;
                 pb += kb;
             };
-            auto multiply = [&](int stage) {
+            // mode 0: everything; 1: column groups 0, 1; 2: column groups 2, 3
+            auto multiply = [&](int stage, auto MODE) {
+                constexpr int mode = decltype(MODE)::value;
+                constexpr int J0 = mode == 2 ? TN / 2 : 0, J1 = mode == 1 ? TN / 2 : TN;
                 const double* st = stage ? smem1 : smem;
 #pragma unroll
                 for (int kk = 0; kk < BK / 4; ++kk) {
                     double fa[TM], fb[TN];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[i] = fragA(st, wm + i * 16 + l15, kk * 4 + l4);
+                    for (int i = 0; i < TM; ++i) fa[i] = fragA(st, wm + sub16<TM>(i) + l15, kk * 4 + l4);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[j] = fragB(st, wn + j * 16 + l15, kk * 4 + l4);
+                    for (int j = J0; j < J1; ++j) fb[j] = fragB(st, wn + sub16<TN>(j) + l15, kk * 4 + l4);
                     if (scaled) {
                         const double sc = sks[stage][kk * 4 + l4];
 #pragma unroll
                         for (int i = 0; i < TM; ++i) fa[i] *= sc;
                     }
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = J0; j < J1; ++j)
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
                             acc[j][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[j], fa[i], acc[j][i], 0, 0, 0);
                 }
             };
-            // waiting for tile j leaves the warm-up load issued after it outstanding, if there was one
-            issue(0);
-            if (kt0 + 1 < kt1) warm();
-            int kt = kt0;
-            for (; kt + 1 < kt1; kt += 2) {
-                __builtin_amdgcn_s_waitcnt(0x0f71);  // vmcnt(1): this wave's part of tile kt is in LDS
-                __syncthreads();                     // ... and every other wave's; stage 1 is free again
-                issue(1);
-                const bool more = kt + 2 < kt1;
-                if (more) warm();
-                multiply(0);
-                if (more) __builtin_amdgcn_s_waitcnt(0x0f71);
-                else __builtin_amdgcn_s_waitcnt(0x0f70);
-                __syncthreads();
-                if (more) {
-                    issue(0);
-                    if (kt + 3 < kt1) warm();
+            // `cnt` K tiles in one shape; rem: tiles not multiplied yet, all segments together.  cnt is even unless the
+            // segment is the last one.  Waiting for a tile leaves the warm-up load issued after it outstanding, if there was one.
+            int rem = kt1 - kt0;
+            auto segment = [&](auto MODE, int cnt) {
+                for (; cnt >= 2; cnt -= 2, rem -= 2) {
+                    __builtin_amdgcn_s_waitcnt(0x0f71);  // vmcnt(1): this wave's part of the tile is in LDS
+                    __syncthreads();                     // ... and every other wave's; stage 1 is free again
+                    issue(1);
+                    const bool more = rem > 2;
+                    if (more) warm();
+                    multiply(0, MODE);
+                    if (more) __builtin_amdgcn_s_waitcnt(0x0f71);
+                    else __builtin_amdgcn_s_waitcnt(0x0f70);
+                    __syncthreads();
+                    if (more) {
+                        issue(0);
+                        if (rem > 3) warm();
+                    }
+                    multiply(1, MODE);
                 }
-                multiply(1);
+                if (cnt == 1) {
+                    __builtin_amdgcn_s_waitcnt(0x0f70);
+                    __syncthreads();
+                    multiply(0, MODE);
+                    rem -= 1;
+                }
+            };
+            int n_first = 0, n_last = 0;   // half-shaped K tiles before / after the full ones, in the order of the walk
+            if (SK == 1 || SK == 2) {
+                const int kbeg = klo + kt0 * BK, kend = klo + kt1 * BK, nmid = n0 + BN / 2;
+                const int nh = SK == 1 ? min(max((kend - nmid) / BK, 0), rem) : min(max((nmid - kbeg) / BK, 0), rem);
+                const bool at_end = (SK == 1) != down;   // SK 1: the half tiles are the last of an ascending walk
+                if (at_end ? !((rem - nh) & 1) : !(nh & 1)) {   // a segment that another one follows has an even count
+                    if (at_end) n_last = nh;
+                    else n_first = nh;
+                }
             }
-            if (kt < kt1) {
-                __builtin_amdgcn_s_waitcnt(0x0f70);
-                __syncthreads();
-                multiply(0);
-            }
+            issue(0);
+            if (rem > 1) warm();
+            using HALF = std::integral_constant<int, SK == 1 ? 2 : SK == 2 ? 1 : 0>;
+            if (SK != 0) segment(HALF{}, n_first);
+            segment(std::integral_constant<int, 0>{}, rem - n_last);   // rem: n_first is done
+            if (SK != 0) segment(HALF{}, n_last);
         };
         if (AKC && g.kscale != nullptr) run(std::true_type{});
         else run(std::false_type{});
@@ -449,9 +495,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[kk][i] = sfrag<BM, AKC>(st, wm + i * 16 + l15, kk * 4 + l4);
+                for (int i = 0; i < TM; ++i) fa[kk][i] = sfrag<BM, AKC>(st, wm + sub16<TM>(i) + l15, kk * 4 + l4);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[kk][j] = sfrag<BN, BKC>(st + LA, wn + j * 16 + l15, kk * 4 + l4);
+                for (int j = 0; j < TN; ++j) fb[kk][j] = sfrag<BN, BKC>(st + LA, wn + sub16<TN>(j) + l15, kk * 4 + l4);
             }
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk)
@@ -521,9 +567,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             for (int kk = 0; kk < BK / 4; ++kk) {
                 double fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = sfrag<BM, AKC>(sA, wm + i * 16 + l15, kk * 4 + l4);
+                for (int i = 0; i < TM; ++i) fa[i] = sfrag<BM, AKC>(sA, wm + sub16<TM>(i) + l15, kk * 4 + l4);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = sfrag<BN, BKC>(sB, wn + j * 16 + l15, kk * 4 + l4);
+                for (int j = 0; j < TN; ++j) fb[j] = sfrag<BN, BKC>(sB, wn + sub16<TN>(j) + l15, kk * 4 + l4);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -562,9 +608,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             for (int kk = 0; kk < BK / 4; ++kk) {
                 double fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = sfrag<BM, AKC>(sA, wm + i * 16 + l15, kk * 4 + l4);
+                for (int i = 0; i < TM; ++i) fa[i] = sfrag<BM, AKC>(sA, wm + sub16<TM>(i) + l15, kk * 4 + l4);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = sfrag<BN, BKC>(sB, wn + j * 16 + l15, kk * 4 + l4);
+                for (int j = 0; j < TN; ++j) fb[j] = sfrag<BN, BKC>(sB, wn + sub16<TN>(j) + l15, kk * 4 + l4);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -577,8 +623,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     // epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4) + 4r]
     double* Cb = g.C + (g.splitk > 1 ? (long)ks * g.slab : 0);
     const bool plain = RD != 0 || g.splitk > 1 || g.beta == 0.0;   // the row-dot variants are beta == 0 only: no old-value path in them
+    const int part = 2 * bj + (wave >> 1);   // row-dot parts: two per tile column (one per wave column)
     if (RD == 2 && m0 + BM <= g.M && n0 + BN <= g.N) {
-        store_rowdot_full<TM, TN>(g, acc, Cb, m0 + wm, n0 + wn, l15, l4);
+        store_rowdot_full<TM, TN>(g, acc, Cb, m0 + wm, n0 + wn, part, l15, l4);
         return;
     }
     if (m0 + BM <= g.M && n0 + BN <= g.N) {
@@ -588,35 +635,35 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         const long s4 = 4 * g.ldc;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            double* cj = c0 + (long)(16 * j) * g.ldc;
+            double* cj = c0 + (long)sub16<TN>(j) * g.ldc;
             if (plain) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) cj[r * s4 + 16 * i] = g.alpha * acc[j][i][r];
+                    for (int i = 0; i < TM; ++i) cj[r * s4 + sub16<TM>(i)] = g.alpha * acc[j][i][r];
             } else {
                 double old[4][TM];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) old[r][i] = cj[r * s4 + 16 * i];
+                    for (int i = 0; i < TM; ++i) old[r][i] = cj[r * s4 + sub16<TM>(i)];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) cj[r * s4 + 16 * i] = g.alpha * acc[j][i][r] + g.beta * old[r][i];
+                    for (int i = 0; i < TM; ++i) cj[r * s4 + sub16<TM>(i)] = g.alpha * acc[j][i][r] + g.beta * old[r][i];
             }
         }
-        if (RD) rowdot_epilogue<TM, TN, true, RD>(g, acc, m0 + wm, n0 + wn, l15, l4);
+        if (RD) rowdot_epilogue<TM, TN, true, RD>(g, acc, m0 + wm, n0 + wn, part, l15, l4);
         return;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm + i * 16 + l15;
+            const int m = m0 + wm + sub16<TM>(i) + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn + j * 16 + l4 + 4 * r;
+                const int n = n0 + wn + sub16<TN>(j) + l4 + 4 * r;
                 if (m < g.M && n < g.N) {
                     double* c = Cb + m + (long)n * g.ldc;
                     const double v = g.alpha * acc[j][i][r];
@@ -624,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 }
             }
         }
-    if (RD && n0 + wn < g.N) rowdot_epilogue<TM, TN, false, RD>(g, acc, m0 + wm, n0 + wn, l15, l4);
+    if (RD) rowdot_epilogue<TM, TN, false, RD>(g, acc, m0 + wm, n0 + wn, part, l15, l4);   // a part without columns gets zeros
 }
 
 __global__ void splitk_reduce_kernel(double* __restrict__ C, long ldc, const double* __restrict__ W,
@@ -639,13 +686,22 @@ __global__ void splitk_reduce_kernel(double* __restrict__ C, long ldc, const dou
     *c = beta == 0.0 ? s : s + beta * *c;
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int SK = 0>
 void launch(hipStream_t st, int a_kc, int b_kc, const GemmArgs& g, int grid) {
     const dim3 blk(256);
-    if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), dim3(grid), blk, 0, st, g);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), dim3(grid), blk, 0, st, g);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), dim3(grid), blk, 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true>), dim3(grid), blk, 0, st, g);
+    if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false, 0, SK>), dim3(grid), blk, 0, st, g);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true, 0, SK>), dim3(grid), blk, 0, st, g);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false, 0, SK>), dim3(grid), blk, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<TM, TN, true, true, 0, SK>), dim3(grid), blk, 0, st, g);
+}
+
+// which half-tile skipping instantiation of the 128-tile kernel a product takes (see the kernel's direct-to-LDS loop)
+int half_skip_kind(int flags) {
+    static const bool off = getenv("GPX_NO_HALF_SKIP") != nullptr;   // measurement only
+    if (off || (flags & GEMM_NO_HALF_SKIP)) return 0;
+    const int kf = flags & (GEMM_KLO_M | GEMM_KLO_N | GEMM_KHI_M | GEMM_KHI_N);
+    if (flags & GEMM_LOWER) return 0;
+    return kf == GEMM_KHI_N ? 1 : kf == GEMM_KLO_N ? 2 : 0;
 }
 
 // ---- optional per-launch HIP-event timing of the large GEMMs (bench.py's roofline leg) -------
@@ -679,7 +735,7 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     if (M <= 0 || N <= 0) return GPX_OK;
     if (rd && rd->R1) {
         if (a_kc || b_kc || beta != 0.0 || splitk > 1 || (flags & (GEMM_LOWER | GEMM_TILE64)) || (rd->E && !(rd->evec && rd->R2)) || (!rd->E && (rd->evec || rd->R2))) return GPX_ERR_ARG;
-        flags |= GEMM_TILE128;   // the parts are the 64-column halves of 128-tiles
+        flags |= GEMM_TILE128;   // the parts are the columns one wave of a 128-tile owns
     }
     if (kscale && (!a_kc || (reinterpret_cast<uintptr_t>(kscale) & 15))) return GPX_ERR_ARG;
     if (M > 0x7fffffffL - 256 || N > 0x7fffffffL - 256 || K > 0x7fffffffL - 256) return GPX_ERR_ARG;
@@ -727,8 +783,12 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
             g_prof.skipped++;
         }
     }
+    const int sk = bt == 128 ? half_skip_kind(flags) : 0;
     if (g.R1 && g.E) hipLaunchKernelGGL((gemm_kernel<4, 4, false, false, 2>), dim3((unsigned)grid), dim3(256), 0, st, g);
+    else if (g.R1 && sk == 1) hipLaunchKernelGGL((gemm_kernel<4, 4, false, false, 1, 1>), dim3((unsigned)grid), dim3(256), 0, st, g);
     else if (g.R1) hipLaunchKernelGGL((gemm_kernel<4, 4, false, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, g);
+    else if (bt == 128 && sk == 1) launch<4, 4, 1>(st, a_kc, b_kc, g, (int)grid);
+    else if (bt == 128 && sk == 2) launch<4, 4, 2>(st, a_kc, b_kc, g, (int)grid);
     else if (bt == 128) launch<4, 4>(st, a_kc, b_kc, g, (int)grid);
     else if (bt == 64) launch<2, 2>(st, a_kc, b_kc, g, (int)grid);
     else launch<1, 1>(st, a_kc, b_kc, g, (int)grid);

@@ -15,6 +15,7 @@
 #define GEMM_FORCE_SQUARES 2048  // the square order even where it does not pay (few squares; tests)
 #define GEMM_NO_BAND 4096   // LOWER products: keep the diagonal tiles in the main launch (measurement only)
 #define GEMM_NO_TILE32 8192  // keep 64x64 tiles for products of at most 64 of them (measurement only)
+#define GEMM_NO_HALF_SKIP 16384  // 128-tiles: multiply every K tile of a triangular operand in full (measurement only)
 // internal to gemm_f64.hip (set by the host side, not by callers):
 #define GEMM_STRICT_LOWER (1 << 16)  // main launch of a LOWER product: tiles strictly below the diagonal only
 #define GEMM_DIAG_BAND (1 << 17)     // second launch: the 128x128 diagonal blocks as three 64x64 tiles each

@@ -53,10 +53,10 @@ int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, 
                     const double* A, long lda, const double* B, long ldb, double beta, double* C,
                     long ldc, int flags, double* work, long work_doubles, const double* kscale = nullptr);
 
-// C = alpha op(A) op(B)^T (128-tiles, no split-K) with a row-dot epilogue: per 64-column part p = n / 64 of the output
+// C = alpha op(A) op(B)^T (128-tiles, no split-K) with a row-dot epilogue: per part p (64 columns) of the output
 //   R1[p*ldr + m] = sum_{n in part p} C(m,n) * E(m,n)     (E == NULL: E = C, the row sums of squares)
 //   R2[p*ldr + m] = sum_{n in part p} E(m,n) * evec[n]    (E, evec and R2 come together or not at all)
-// (ceil(N/64) parts, ldr >= M; every part of every row m < M is written, deterministically)
+// (2*ceil(N/128) parts, column n in part 2*(n/128) + (n%64)/32; ldr >= M; every part of every row m < M is written, deterministically)
 struct GemmRowdot {
     const double* E; long lde;
     const double* evec;

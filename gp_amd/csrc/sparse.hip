@@ -213,7 +213,7 @@ struct Sparse {
     HypView h;
 
     bool mfma() const { return c->mfma_pairwise && gpx_mfma_pair_supported(d); }
-    long nparts() const { return (m + 63) / 64; }   // 64-column parts of the GEMM row-dot epilogue
+    long nparts() const { return 2 * ((m + 127) / 128); }   // parts of the GEMM row-dot epilogue (gpx_internal.h)
     // V = Kxu Lu^-T with rowsum(V o V) from the epilogue, then Gamma (FITC.cpp:213-216)
     int v_and_gamma(const double* Winv_u, const double* r, double sn2, double sf2, double* g, double* p) {
         GemmRowdot rd = {};

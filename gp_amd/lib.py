@@ -21,7 +21,7 @@ _d = C.c_double
 
 GEMM_LOWER, GEMM_KLO_M, GEMM_KLO_N, GEMM_KHI_M, GEMM_KHI_N = 1, 2, 4, 8, 16
 GEMM_HEAVY_LAST, GEMM_TILE64, GEMM_TILE128 = 32, 64, 128
-GEMM_NO_SQUARES, GEMM_FORCE_SQUARES, GEMM_NO_BAND, GEMM_NO_TILE32 = 1024, 2048, 4096, 8192
+GEMM_NO_SQUARES, GEMM_FORCE_SQUARES, GEMM_NO_BAND, GEMM_NO_TILE32, GEMM_NO_HALF_SKIP = 1024, 2048, 4096, 8192, 16384
 
 
 class GpxError(RuntimeError):
@@ -131,7 +131,7 @@ def dgemm_rowdot(A, B, E=None, evec=None, alpha=1.0, flags=0):
     B = np.asarray(B, dtype=np.float64)
     M, K = A.shape
     N = B.shape[0]
-    parts = (N + 63) // 64
+    parts = 2 * ((N + 127) // 128)
     dA, dB = DeviceBuffer.from_numpy(colmajor(A)), DeviceBuffer.from_numpy(colmajor(B))
     dC, dR1 = DeviceBuffer(M * N), DeviceBuffer(parts * M)
     dE = DeviceBuffer.from_numpy(colmajor(E)) if E is not None else None

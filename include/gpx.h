@@ -39,8 +39,9 @@ int gpx_dgemm_kscale(int b_kc, int64_t M, int64_t N, int64_t K, double alpha, co
                      const double* kscale, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
                      int flags, double* work, int64_t work_doubles);
 
-/* C = alpha * A * B^T (both operands M/N-contiguous) together with the row statistics of the result, per 64-column
- * part p = n / 64 (ceil(N/64) parts, ldr >= M, every part of every row written, deterministic):
+/* C = alpha * A * B^T (both operands M/N-contiguous) together with the row statistics of the result in 2*ceil(N/128)
+ * parts of 64 columns (column n belongs to part p = 2*(n/128) + (n%64)/32: the columns one wave of the 128-tile owns;
+ * callers sum over the parts; ldr >= M, every part of every row written, deterministic):
  *   R1[p*ldr + m] = sum_{n in part p} C(m,n) * E(m,n)     (E == NULL: E = C, row sums of squares)
  *   R2[p*ldr + m] = sum_{n in part p} E(m,n) * evec[n]    (E, evec, R2 all given or all NULL)
  * Replaces the separate passes diag(Kxu Kuu^-1 Kux) = rowsum(V o V) (FITC.cpp:215), rowsum(C o Kxu) and Kxu * a

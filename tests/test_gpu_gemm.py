@@ -159,7 +159,7 @@ def test_gemm_kscale_weighted_gram(shape):
 @pytest.mark.parametrize("with_e", [False, True])
 def test_gemm_rowdot_epilogue_ragged_shapes(shape, with_e):
     """The row-dot epilogue (gpx_dgemm_rowdot: rowsum(V o V), rowsum(C o Kxu) and Kxu a of FITC.cpp:215-220, 262-263
-    leave the GEMM that forms V / C) against NumPy, full and edge tiles, per 64-column part; also with the triangular
+    leave the GEMM that forms V / C) against NumPy, full and edge tiles, per part of 64 columns; also with the triangular
     K range the V product uses."""
     lib = _lib()
     M, N, K = shape
@@ -171,10 +171,11 @@ def test_gemm_rowdot_epilogue_ragged_shapes(shape, with_e):
     ref = 0.7 * A @ B.T
     assert np.max(np.abs(C - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))) * K
     W = E if with_e else ref
-    parts = (N + 63) // 64
+    parts = 2 * ((N + 127) // 128)
     assert R1.shape == (parts, M)
+    cols = np.arange(N)
     for p in range(parts):
-        sl = slice(64 * p, min(N, 64 * p + 64))
+        sl = cols[2 * (cols // 128) + (cols % 64) // 32 == p]   # the columns one wave of the 128-tile owns
         r1 = np.sum(ref[:, sl] * W[:, sl], axis=1)
         assert np.max(np.abs(R1[p] - r1)) <= 1e-11 * max(1.0, np.max(np.abs(r1))) * K
         if with_e:
