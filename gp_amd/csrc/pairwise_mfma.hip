@@ -636,12 +636,31 @@ __global__ void augment_kernel(const double* __restrict__ Xt, long ldx, long cnt
     }
 }
 
-__global__ void colsum_finish_kernel(const double* __restrict__ cpart, int nwg, long ldua, double* __restrict__ cvec) {
-    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= ldua) return;
-    double s = 0.0;
-    for (int w = 0; w < nwg; ++w) s += cpart[(long)w * ldua + b];
-    cvec[b] = s;
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const double* __restrict__ cpart, int nwg, long ldua, double* __restrict__ cvec) {
+    // 32 columns x 8 row groups per block (one thread per column walking all nwg rows is a chain of nwg dependent loads:
+    // 200 us at nwg = 512); fixed order of the partial sums: deterministic
+    __shared__ double red[8][33];
+    const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const long b = (long)blockIdx.x * 32 + c;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (b < ldua) {
+        int w = q;
+        for (; w + 24 < nwg; w += 32) {
+            s0 += cpart[(long)w * ldua + b];
+            s1 += cpart[(long)(w + 8) * ldua + b];
+            s2 += cpart[(long)(w + 16) * ldua + b];
+            s3 += cpart[(long)(w + 24) * ldua + b];
+        }
+        for (; w < nwg; w += 8) s0 += cpart[(long)w * ldua + b];
+    }
+    red[q][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && b < ldua) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][c];
+        cvec[b] = s;
+    }
 }
 
 // out[i] = sum_wg spart[wg][i] + sum_b u~_ib^2 colsum_b  (i < d);  out[d] = sum_ab Q_ab;  out[d+1] = 0
@@ -799,7 +818,7 @@ int gpx_mfma_pair_trace(hipStream_t st, const double* Xa, long n, const double* 
     } else {
         GPX_KK_SWITCH(GPX_TRACE_K1, kk_of(d), (unsigned)grid, st, g);
     }
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((g.ldua + 255) / 256)), dim3(256), 0, st, cpart, grid, g.ldua, cvec);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((g.ldua + 31) / 32)), dim3(256), 0, st, cpart, grid, g.ldua, cvec);
     hipLaunchKernelGGL(trace_mfma_finish_kernel, dim3(d + 1), dim3(256), 0, st, spart, grid, n2, Ua, g.ldua, m, cvec, d, out);
     gpx_pair_prof_close(st, slot);
     HIP_TRY(hipGetLastError());

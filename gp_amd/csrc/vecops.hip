@@ -4,11 +4,14 @@
 
 namespace {
 
-// y[i] = beta*y[i] + alpha * sum_k A[i + k*lda] x[k]; 64 rows per workgroup, 4 waves split K
-__global__ __launch_bounds__(256) void gemv_n_kernel(long M, long K, double alpha, const double* __restrict__ A,
-                                                     long lda, const double* __restrict__ x, double beta,
-                                                     double* __restrict__ y, int tri) {
-    __shared__ double red[4][64];
+// y[i] = beta*y[i] + alpha * sum_k A[i + k*lda] x[k]; 64 rows per workgroup, 16 waves split K (the last row blocks of a
+// triangular factor are chains of dependent load batches: with 4 waves 278 us at n = 8192, a fifth of them needed)
+constexpr int GEMV_NW = 16;
+__global__ __launch_bounds__(64 * GEMV_NW) void gemv_n_kernel(long M, long K, double alpha, const double* __restrict__ A,
+                                                              long lda, const double* __restrict__ x, double beta,
+                                                              double* __restrict__ y, int tri) {
+    constexpr int NW = GEMV_NW;
+    __shared__ double red[NW][64];
     // lower triangular A: full columns are those left of this row block; the diagonal block is masked
     const long Kf = tri ? min(K, (long)blockIdx.x * 64) : K;
     if (tri) K = min(K, ((long)blockIdx.x + 1) * 64);
@@ -20,35 +23,37 @@ __global__ __launch_bounds__(256) void gemv_n_kernel(long M, long K, double alph
         long k = w;
         // eight loads in flight per lane first: the long rows of a triangular factor are bound by load latency
         double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-        for (; k + 28 < Kf; k += 32) {
+        for (; k + 7 * NW < Kf; k += 8 * NW) {
             s0 = fma(a[k * lda], x[k], s0);
-            s1 = fma(a[(k + 4) * lda], x[k + 4], s1);
-            s2 = fma(a[(k + 8) * lda], x[k + 8], s2);
-            s3 = fma(a[(k + 12) * lda], x[k + 12], s3);
-            t0 = fma(a[(k + 16) * lda], x[k + 16], t0);
-            t1 = fma(a[(k + 20) * lda], x[k + 20], t1);
-            t2 = fma(a[(k + 24) * lda], x[k + 24], t2);
-            t3 = fma(a[(k + 28) * lda], x[k + 28], t3);
+            s1 = fma(a[(k + NW) * lda], x[k + NW], s1);
+            s2 = fma(a[(k + 2 * NW) * lda], x[k + 2 * NW], s2);
+            s3 = fma(a[(k + 3 * NW) * lda], x[k + 3 * NW], s3);
+            t0 = fma(a[(k + 4 * NW) * lda], x[k + 4 * NW], t0);
+            t1 = fma(a[(k + 5 * NW) * lda], x[k + 5 * NW], t1);
+            t2 = fma(a[(k + 6 * NW) * lda], x[k + 6 * NW], t2);
+            t3 = fma(a[(k + 7 * NW) * lda], x[k + 7 * NW], t3);
         }
         s0 += t0;
         s1 += t1;
         s2 += t2;
         s3 += t3;
-        for (; k + 12 < Kf; k += 16) {
+        for (; k + 3 * NW < Kf; k += 4 * NW) {
             s0 = fma(a[k * lda], x[k], s0);
-            s1 = fma(a[(k + 4) * lda], x[k + 4], s1);
-            s2 = fma(a[(k + 8) * lda], x[k + 8], s2);
-            s3 = fma(a[(k + 12) * lda], x[k + 12], s3);
+            s1 = fma(a[(k + NW) * lda], x[k + NW], s1);
+            s2 = fma(a[(k + 2 * NW) * lda], x[k + 2 * NW], s2);
+            s3 = fma(a[(k + 3 * NW) * lda], x[k + 3 * NW], s3);
         }
-        for (; k < Kf; k += 4) s0 = fma(a[k * lda], x[k], s0);
+        for (; k < Kf; k += NW) s0 = fma(a[k * lda], x[k], s0);
         if (tri)
-            for (; k < K; k += 4)
+            for (; k < K; k += NW)
                 if (k <= i) s0 = fma(a[k * lda], x[k], s0);
     }
     red[w][l] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (w == 0 && i < M) {
-        const double t = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; q += 4) t += (red[q][l] + red[q + 1][l]) + (red[q + 2][l] + red[q + 3][l]);
         y[i] = beta == 0.0 ? alpha * t : beta * y[i] + alpha * t;
     }
 }
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(long M, long K, double alph
 int gpx_gemv_n(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
                double beta, double* y, int tri) {
     if (M <= 0) return GPX_OK;
-    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, st, M, K, alpha, A, lda, x,
+    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64 * GEMV_NW), 0, st, M, K, alpha, A, lda, x,
                        beta, y, tri);
     return GPX_OK;
 }
