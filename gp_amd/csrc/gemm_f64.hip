@@ -46,14 +46,15 @@ struct GemmArgs : TileOrder {
     double* R1; double* R2; long ldr;
 };
 
-// Offset of a wave's i-th 16-row (16-column) group inside the block tile, relative to the wave's base.  With four groups per
-// wave (128-tiles) the ownership is INTERLEAVED: groups 0, 1 lie in the first 64 rows of the tile and groups 2, 3 in the
-// second 64 (wave base 32 (wave & 1)), so that a K range that only concerns one half of the tile (triangular operands
-// cut at 64) halves the work of EVERY wave alike.
+// Offset of a wave's j-th 16-column group inside the block tile, relative to the wave's base column.  With four groups per
+// wave (128-tiles) the column ownership is INTERLEAVED: groups 0, 1 lie in the first 64 columns of the tile and groups
+// 2, 3 in the second 64 (wave base 32 (wave >> 1)), so that a K range that only concerns one half of the tile's columns
+// (triangular operands cut at 64) halves the work of EVERY wave alike.  (Rows stay contiguous per wave, 64 (wave & 1) +
+// 16 i: interleaving them as well cost the exact n = 65536 evaluation 1.2 %, same-box A/B, and nothing uses it.)
 template <int T>
 __device__ __forceinline__ constexpr int sub16(int i) { return T == 4 ? (i & 1) * 16 + (i >> 1) * 64 : 16 * i; }
 
-// the row-dot epilogue of one wave: acc[j][i][r] = C(mb + sub16(i) + l15, nb + sub16(j) + l4 + 4 r) / alpha; part: the wave's
+// the row-dot epilogue of one wave: acc[j][i][r] = C(mb + 16 i + l15, nb + sub16(j) + l4 + 4 r) / alpha; part: the wave's
 // slot among the 2 * ceil(N / 128) row-dot parts
 // RD == 1: E = C (row sums of squares, R1 only); RD == 2: E, evec, R1 and R2 all given
 template <int TM, int TN, bool FULL, int RD>
@@ -76,7 +77,7 @@ __device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const v4d (&a
                     if (TN == 4 && j == 2 && r == 0) ep += 8 * estep;   // groups 2, 3: the second 64 columns of the tile
                     ev = vp[sub16<TN>(j) + 4 * r];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) e[i] = ep[sub16<TM>(i)];
+                    for (int i = 0; i < TM; ++i) e[i] = ep[16 * i];
                     ep += estep;
                 } else {   // edge tiles: clamped addresses and 0/1 masks instead of guarded loads (no divergent branches)
                     const int n = nb + sub16<TN>(j) + l4 + 4 * r;
@@ -85,7 +86,7 @@ __device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const v4d (&a
                     ev = g.evec[min(n, g.N - 1)] * nmask;
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
-                        const int m = mb + sub16<TM>(i) + l15;
+                        const int m = mb + 16 * i + l15;
                         e[i] = col[min(m, g.M - 1)] * (m < g.M ? nmask : 0.0);
                     }
                 }
@@ -113,7 +114,7 @@ __device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const v4d (&a
             b += __shfl_xor(b, 16, 64);
             b += __shfl_xor(b, 32, 64);
         }
-        const int m = mb + sub16<TM>(i) + l15;
+        const int m = mb + 16 * i + l15;
         if (l4 == 0 && (FULL || m < g.M)) {
             g.R1[off + m] = a;
             if (RD == 2) g.R2[off + m] = b;
@@ -144,13 +145,13 @@ __device__ __forceinline__ void store_rowdot_full(const GemmArgs& g, const v4d (
         for (int r = 0; r < 4; ++r) {
             ev[r] = vp[sub16<TN>(j) + 4 * r];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) e[r][i] = ep[sub16<TM>(i)];
+            for (int i = 0; i < TM; ++i) e[r][i] = ep[16 * i];
             ep += estep;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) cp[sub16<TM>(i)] = g.alpha * acc[j][i][r];
+            for (int i = 0; i < TM; ++i) cp[16 * i] = g.alpha * acc[j][i][r];
             cp += cstep;
         }
 #pragma unroll
@@ -171,8 +172,8 @@ __device__ __forceinline__ void store_rowdot_full(const GemmArgs& g, const v4d (
         b += __shfl_xor(b, 16, 64);
         b += __shfl_xor(b, 32, 64);
         if (l4 == 0) {
-            g.R1[off + mb + sub16<TM>(i) + l15] = a;
-            g.R2[off + mb + sub16<TM>(i) + l15] = b;
+            g.R1[off + mb + 16 * i + l15] = a;
+            g.R2[off + mb + 16 * i + l15] = b;
         }
     }
 }
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave & 1) * (TM == 4 ? 32 : 16 * TM), wn = (wave >> 1) * (TN == 4 ? 32 : 16 * TN);   // see sub16
+    const int wm = (wave & 1) * (16 * TM), wn = (wave >> 1) * (TN == 4 ? 32 : 16 * TN);   // see sub16
     const int l15 = lane & 15, l4 = lane >> 4;
 
     v4d acc[TN][TM];
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 for (int kk = 0; kk < BK / 4; ++kk) {
                     double fa[TM], fb[TN];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[i] = fragA(st, wm + sub16<TM>(i) + l15, kk * 4 + l4);
+                    for (int i = 0; i < TM; ++i) fa[i] = fragA(st, wm + 16 * i + l15, kk * 4 + l4);
 #pragma unroll
                     for (int j = J0; j < J1; ++j) fb[j] = fragB(st, wn + sub16<TN>(j) + l15, kk * 4 + l4);
                     if (scaled) {
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[kk][i] = sfrag<BM, AKC>(st, wm + sub16<TM>(i) + l15, kk * 4 + l4);
+                for (int i = 0; i < TM; ++i) fa[kk][i] = sfrag<BM, AKC>(st, wm + 16 * i + l15, kk * 4 + l4);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) fb[kk][j] = sfrag<BN, BKC>(st + LA, wn + sub16<TN>(j) + l15, kk * 4 + l4);
             }
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             for (int kk = 0; kk < BK / 4; ++kk) {
                 double fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = sfrag<BM, AKC>(sA, wm + sub16<TM>(i) + l15, kk * 4 + l4);
+                for (int i = 0; i < TM; ++i) fa[i] = sfrag<BM, AKC>(sA, wm + 16 * i + l15, kk * 4 + l4);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) fb[j] = sfrag<BN, BKC>(sB, wn + sub16<TN>(j) + l15, kk * 4 + l4);
 #pragma unroll
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             for (int kk = 0; kk < BK / 4; ++kk) {
                 double fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = sfrag<BM, AKC>(sA, wm + sub16<TM>(i) + l15, kk * 4 + l4);
+                for (int i = 0; i < TM; ++i) fa[i] = sfrag<BM, AKC>(sA, wm + 16 * i + l15, kk * 4 + l4);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) fb[j] = sfrag<BN, BKC>(sB, wn + sub16<TN>(j) + l15, kk * 4 + l4);
 #pragma unroll
@@ -640,17 +641,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) cj[r * s4 + sub16<TM>(i)] = g.alpha * acc[j][i][r];
+                    for (int i = 0; i < TM; ++i) cj[r * s4 + 16 * i] = g.alpha * acc[j][i][r];
             } else {
                 double old[4][TM];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) old[r][i] = cj[r * s4 + sub16<TM>(i)];
+                    for (int i = 0; i < TM; ++i) old[r][i] = cj[r * s4 + 16 * i];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) cj[r * s4 + sub16<TM>(i)] = g.alpha * acc[j][i][r] + g.beta * old[r][i];
+                    for (int i = 0; i < TM; ++i) cj[r * s4 + 16 * i] = g.alpha * acc[j][i][r] + g.beta * old[r][i];
             }
         }
         if (RD) rowdot_epilogue<TM, TN, true, RD>(g, acc, m0 + wm, n0 + wn, part, l15, l4);
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm + sub16<TM>(i) + l15;
+            const int m = m0 + wm + 16 * i + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + wn + sub16<TN>(j) + l4 + 4 * r;

@@ -1,0 +1,11 @@
+#!/bin/bash
+# A/B of builds of libgpx.so on ONE box, exact n = 65536 only; usage: run_ab_exact.sh <tag> <tag> ... (tools/ab/libgpx_<tag>.so)
+set -e
+cd "$(dirname "$0")/../.."
+cp gp_amd/libgpx.so /tmp/libgpx_keep.so
+for v in "$@"; do
+  cp tools/ab/libgpx_$v.so gp_amd/libgpx.so
+  echo "== $v"
+  timeout -k 10 300 python bench.py --workload exact --steps 2 --warmup 1 --no-cpu-baseline --predict-t 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['achieved'])"
+done
+cp /tmp/libgpx_keep.so gp_amd/libgpx.so
