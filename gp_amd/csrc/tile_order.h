@@ -160,10 +160,12 @@ inline TilePlan plan_tiles(long M, long N, int flags, int splitk, bool has_kscal
     {
         const long t128 = ((M + 127) / 128) * ((N + 127) / 128) / ((flags & GEMM_LOWER) ? 2 : 1);
         if (t128 * (splitk > 1 ? splitk : 1) < 384) bt = 64;
-        // a 64x64 tile is bound by the matrix pipe of the ONE CU it runs on (0.43 us per 16-deep K step): products
-        // with at most 64 such tiles (the chains below 1024 rows) take 32x32 tiles, four times the CUs per product
+        // a 64x64 tile is bound by the matrix pipe of the ONE CU it runs on (0.43 us per 16-deep K step) and the longest
+        // tile of a triangular product bounds the launch: products with at most 1024 such tiles (the chains of 2048 rows
+        // and less) take 32x32 tiles, four times the workgroups per product (exact n = 8192 on one box: 14.67 ms with the
+        // limit at 64 tiles, 14.34 at 256, 14.07 at 1024)
         const long t64 = ((M + 63) / 64) * ((N + 63) / 64) / ((flags & GEMM_LOWER) ? 2 : 1);
-        static const long t32max = [] { const char* e = getenv("GPX_TILE32_MAX"); return e ? atol(e) : 64L; }();
+        static const long t32max = [] { const char* e = getenv("GPX_TILE32_MAX"); return e ? atol(e) : 1024L; }();
         if (bt == 64 && t64 * (splitk > 1 ? splitk : 1) <= t32max && !(flags & GEMM_NO_TILE32)) bt = 32;
     }
     if (flags & GEMM_TILE64) bt = 64;

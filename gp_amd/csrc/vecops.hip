@@ -4,48 +4,51 @@
 
 namespace {
 
-// y[i] = beta*y[i] + alpha * sum_k A[i + k*lda] x[k]; 64 rows per workgroup, 16 waves split K (the last row blocks of a
-// triangular factor are chains of dependent load batches: with 4 waves 278 us at n = 8192, a fifth of them needed)
-constexpr int GEMV_NW = 16;
+// y[i] = beta*y[i] + alpha * sum_k A[i + k*lda] x[k]; 32 rows per workgroup, 16 waves x 2 half-waves split K (the last row
+// blocks of a triangular factor are chains of dependent load batches and ONE CU pulls all their bytes: 278 us at n = 8192
+// with 64 rows and 4 waves per block, 165 us with 16 waves)
+constexpr int GEMV_NW = 16;           // waves per block
+constexpr int GEMV_R = 32;            // rows per block: lanes 0-31 take column k, lanes 32-63 column k + 1
+constexpr int GEMV_KS = 2 * GEMV_NW;  // columns per step of the whole block
 __global__ __launch_bounds__(64 * GEMV_NW) void gemv_n_kernel(long M, long K, double alpha, const double* __restrict__ A,
                                                               long lda, const double* __restrict__ x, double beta,
                                                               double* __restrict__ y, int tri) {
-    constexpr int NW = GEMV_NW;
-    __shared__ double red[NW][64];
+    constexpr int KS = GEMV_KS, R = GEMV_R;
+    __shared__ double red[KS][R + 1];
     // lower triangular A: full columns are those left of this row block; the diagonal block is masked
-    const long Kf = tri ? min(K, (long)blockIdx.x * 64) : K;
-    if (tri) K = min(K, ((long)blockIdx.x + 1) * 64);
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long i = (long)blockIdx.x * 64 + l;
+    const long Kf = tri ? min(K, (long)blockIdx.x * R) : K;
+    if (tri) K = min(K, ((long)blockIdx.x + 1) * R);
+    const int l = threadIdx.x & (R - 1), w = threadIdx.x >> 5;   // w: column slot 0 .. KS-1
+    const long i = (long)blockIdx.x * R + l;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (i < M) {
         const double* a = A + i;
         long k = w;
         // eight loads in flight per lane first: the long rows of a triangular factor are bound by load latency
         double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-        for (; k + 7 * NW < Kf; k += 8 * NW) {
+        for (; k + 7 * KS < Kf; k += 8 * KS) {
             s0 = fma(a[k * lda], x[k], s0);
-            s1 = fma(a[(k + NW) * lda], x[k + NW], s1);
-            s2 = fma(a[(k + 2 * NW) * lda], x[k + 2 * NW], s2);
-            s3 = fma(a[(k + 3 * NW) * lda], x[k + 3 * NW], s3);
-            t0 = fma(a[(k + 4 * NW) * lda], x[k + 4 * NW], t0);
-            t1 = fma(a[(k + 5 * NW) * lda], x[k + 5 * NW], t1);
-            t2 = fma(a[(k + 6 * NW) * lda], x[k + 6 * NW], t2);
-            t3 = fma(a[(k + 7 * NW) * lda], x[k + 7 * NW], t3);
+            s1 = fma(a[(k + KS) * lda], x[k + KS], s1);
+            s2 = fma(a[(k + 2 * KS) * lda], x[k + 2 * KS], s2);
+            s3 = fma(a[(k + 3 * KS) * lda], x[k + 3 * KS], s3);
+            t0 = fma(a[(k + 4 * KS) * lda], x[k + 4 * KS], t0);
+            t1 = fma(a[(k + 5 * KS) * lda], x[k + 5 * KS], t1);
+            t2 = fma(a[(k + 6 * KS) * lda], x[k + 6 * KS], t2);
+            t3 = fma(a[(k + 7 * KS) * lda], x[k + 7 * KS], t3);
         }
         s0 += t0;
         s1 += t1;
         s2 += t2;
         s3 += t3;
-        for (; k + 3 * NW < Kf; k += 4 * NW) {
+        for (; k + 3 * KS < Kf; k += 4 * KS) {
             s0 = fma(a[k * lda], x[k], s0);
-            s1 = fma(a[(k + NW) * lda], x[k + NW], s1);
-            s2 = fma(a[(k + 2 * NW) * lda], x[k + 2 * NW], s2);
-            s3 = fma(a[(k + 3 * NW) * lda], x[k + 3 * NW], s3);
+            s1 = fma(a[(k + KS) * lda], x[k + KS], s1);
+            s2 = fma(a[(k + 2 * KS) * lda], x[k + 2 * KS], s2);
+            s3 = fma(a[(k + 3 * KS) * lda], x[k + 3 * KS], s3);
         }
-        for (; k < Kf; k += NW) s0 = fma(a[k * lda], x[k], s0);
+        for (; k < Kf; k += KS) s0 = fma(a[k * lda], x[k], s0);
         if (tri)
-            for (; k < K; k += NW)
+            for (; k < K; k += KS)
                 if (k <= i) s0 = fma(a[k * lda], x[k], s0);
     }
     red[w][l] = (s0 + s1) + (s2 + s3);
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(64 * GEMV_NW) void gemv_n_kernel(long M, long K, do
     if (w == 0 && i < M) {
         double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < NW; q += 4) t += (red[q][l] + red[q + 1][l]) + (red[q + 2][l] + red[q + 3][l]);
+        for (int q = 0; q < KS; q += 4) t += (red[q][l] + red[q + 1][l]) + (red[q + 2][l] + red[q + 3][l]);
         y[i] = beta == 0.0 ? alpha * t : beta * y[i] + alpha * t;
     }
 }
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(long M, long K, double alph
 int gpx_gemv_n(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
                double beta, double* y, int tri) {
     if (M <= 0) return GPX_OK;
-    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64 * GEMV_NW), 0, st, M, K, alpha, A, lda, x,
+    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((M + GEMV_R - 1) / GEMV_R)), dim3(64 * GEMV_NW), 0, st, M, K, alpha, A, lda, x,
                        beta, y, tri);
     return GPX_OK;
 }
