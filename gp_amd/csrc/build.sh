@@ -7,7 +7,9 @@ mkdir -p obj
 pids=()
 for f in *.hip; do
   o=obj/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ gpx_internal.h -nt "$o" ] || [ kernels.h -nt "$o" ] || [ ctx.h -nt "$o" ] || [ ../../include/gpx.h -nt "$o" ]; then
+  stale=0
+  for h in *.h ../../include/gpx.h; do [ "$h" -nt "$o" ] && stale=1; done   # every header: tile_order.h, gemm_flags.h ... too
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ $stale = 1 ]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -c "$f" -o "$o" &
     pids+=($!)
   fi

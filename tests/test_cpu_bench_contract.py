@@ -1,5 +1,5 @@
 """The JSON line of bench.py, as committed beside the rocprofv3 summary of the same command
-(profiles/r02c_default/bench.json), carries every field of the driver's contract plus the `roofline` and
+(profiles/r02d_default/bench.json), carries every field of the driver's contract plus the `roofline` and
 `cpu_baseline` objects, and its numbers are consistent with one another."""
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r02c_default", "bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02d_default", "bench.json")) as f:
         lines = [l for l in f.read().splitlines() if l.strip()]
     assert len(lines) == 1            # stdout carries exactly one line
     return json.loads(lines[0])

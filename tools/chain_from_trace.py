@@ -13,7 +13,7 @@ evals = [s for k, s in enumerate(starts) if k == 0 or s - starts[k - 1] > 8]
 lo = evals[which]
 hi = evals[evals.index(lo) + 1] if evals.index(lo) + 1 < len(evals) else len(rows)
 sel = rows[lo:hi]
-# a chain: the dispatches of ONE stream between its first base block and the last gemm<2,2> that follows a base block
+# a chain: the dispatches of ONE stream between its first base block and the last gemm<2,2> / gemm<1,1> that follows a base block
 by_stream = {}
 for r in sel:
     by_stream.setdefault(r["Stream_Id"], []).append(r)
@@ -28,7 +28,7 @@ for sid, rs in by_stream.items():
             chain[2] += 1
             chain[4] += e - s
             chain[1] = e
-        elif chain is not None and "gemm_kernel<2, 2" in n:
+        elif chain is not None and ("gemm_kernel<2, 2" in n or "gemm_kernel<1, 1" in n):
             chain[3] += 1
             chain[5] += e - s
             chain[1] = e
