@@ -797,7 +797,8 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
         GemmArgs b = g;
         static_cast<TileOrder&>(b) = plan.band_order;
         b.flags |= g.flags & GEMM_NO_FAST32;
-        launch<2, 2>(st, a_kc, b_kc, b, (int)plan.band_grid);
+        if (plan.band_bt == 32) launch<1, 1>(st, a_kc, b_kc, b, (int)plan.band_grid);
+        else launch<2, 2>(st, a_kc, b_kc, b, (int)plan.band_grid);
     }
     if (g.splitk > 1) {
         const long tot = M * N;

@@ -19,4 +19,5 @@
 // internal to gemm_f64.hip (set by the host side, not by callers):
 #define GEMM_STRICT_LOWER (1 << 16)  // main launch of a LOWER product: tiles strictly below the diagonal only
 #define GEMM_DIAG_BAND (1 << 17)     // second launch: the 128x128 diagonal blocks as three 64x64 tiles each
+#define GEMM_DIAG_BAND32 (1 << 19)   // ... as ten 32x32 tiles each (with GEMM_DIAG_BAND; few diagonal blocks)
 #define GEMM_NO_FAST32 (1 << 18)     // an operand's leading dimension overflows the 32-bit lane offsets of the interior loops

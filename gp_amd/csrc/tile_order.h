@@ -41,7 +41,14 @@ GPX_HD inline bool tile_of_block(const TileOrder& g, int block, int& bi, int& bj
         }
     }
     desc = false;  // walk the K range downwards (direct-to-LDS loop only; any order is correct)
-    if (g.flags & GEMM_DIAG_BAND) {
+    if (g.flags & GEMM_DIAG_BAND32) {
+        // the diagonal 128x128 blocks of a LOWER product, ten 32x32 tiles each (rows 0..3 of the block's lower triangle)
+        const int d = tile / 10, q = tile - 10 * d;
+        const int r = (q >= 1) + (q >= 3) + (q >= 6);
+        bi = 4 * d + r;
+        bj = 4 * d + (q - r * (r + 1) / 2);
+        if (bi >= g.tiles_m) return false;
+    } else if (g.flags & GEMM_DIAG_BAND) {
         // the diagonal 128x128 blocks of a LOWER product, three 64x64 tiles each (see gemm_impl)
         const int d = tile / 3, q = tile - 3 * d;
         bi = 2 * d + (q > 0);
@@ -144,9 +151,10 @@ struct TilePlan {
     TileOrder main;
     long grid;
     int bt;              // 128, 64 or 32
-    bool band;           // LOWER product: second launch over the diagonal blocks (64-tiles)
+    bool band;           // LOWER product: second launch over the diagonal blocks (64-tiles, or 32-tiles: band_bt)
     TileOrder band_order;
     long band_grid;
+    int band_bt;
 };
 
 // Launch plan of C[M x N] with option bits `flags`, `splitk` K slabs (>= 1), optional K-scale operand.
@@ -213,6 +221,7 @@ inline TilePlan plan_tiles(long M, long N, int flags, int splitk, bool has_kscal
     p.bt = bt;
     p.band = band;
     p.band_grid = 0;
+    p.band_bt = 64;
     if (band) {
         TileOrder& b = p.band_order;
         b = g;
@@ -220,9 +229,19 @@ inline TilePlan plan_tiles(long M, long N, int flags, int splitk, bool has_kscal
         b.nsuper = 0;
         b.xcd_rows = 0;
         const int t128 = g.tiles_m;
-        b.tiles_m = b.tiles_n = (int)((M + 63) / 64);
-        b.ntiles = 3 * t128;
-        p.band_grid = 3L * t128;
+        // up to 64 diagonal blocks: 32x32 tiles (the band is one long K loop per tile on a CU of its own: 96 64-tiles with
+        // K = 4096 took 178 us behind a main launch of 1 ms; ten 32-tiles per block are 10/12 of the flops on 3.3 times
+        // the CUs); more blocks fill the chip with 64-tiles
+        p.band_bt = t128 <= 64 && !(flags & GEMM_NO_TILE32) ? 32 : 64;
+        if (p.band_bt == 32) {
+            b.flags |= GEMM_DIAG_BAND32;
+            b.tiles_m = b.tiles_n = (int)((M + 31) / 32);
+            b.ntiles = 10 * t128;
+        } else {
+            b.tiles_m = b.tiles_n = (int)((M + 63) / 64);
+            b.ntiles = 3 * t128;
+        }
+        p.band_grid = b.ntiles;
     }
     return p;
 }

@@ -40,20 +40,22 @@ static int check(const char* name, long M, long N, int flags, int splitk) {
     const int tri = flags & (GEMM_KLO_M | GEMM_KLO_N | GEMM_KHI_M | GEMM_KHI_N);
     const bool one_dep = tri == GEMM_KLO_M || tri == GEMM_KLO_N || tri == GEMM_KHI_M || tri == GEMM_KHI_N;
     if (reversed && !(one_dep && !lower)) ++bad;
-    // band launch: the three 64 x 64 tiles on and below the diagonal of every diagonal 128-block
+    // band launch: the three 64 x 64 (or ten 32 x 32) tiles on and below the diagonal of every diagonal 128-block
     long band_tiles = 0;
     if (p.band) {
         std::map<std::pair<int, int>, int> bs;
-        const long t64 = (M + 63) / 64;
+        const int bbt = p.band_bt, per = 128 / bbt;   // tiles per block side
+        if (bbt != 32 && bbt != 64) ++bad;
+        const long t64 = (M + bbt - 1) / bbt;
         for (long b = 0; b < p.band_grid; ++b) {
             int bi, bj, ks;
             bool desc;
             if (!tile_of_block(p.band_order, (int)b, bi, bj, ks, desc)) continue;
-            if (bi >= t64 || bj > bi || bi / 2 != bj / 2 || ks != 0 || desc) ++bad;
+            if (bi >= t64 || bj > bi || bi / per != bj / per || ks != 0 || desc) ++bad;
             ++bs[{bi, bj}];
         }
         for (long i = 0; i < t64; ++i)
-            for (long j = (i / 2) * 2; j <= i; ++j) {
+            for (long j = (i / per) * per; j <= i; ++j) {
                 ++band_tiles;
                 auto it = bs.find({(int)i, (int)j});
                 if (it == bs.end() || it->second != 1) ++bad;

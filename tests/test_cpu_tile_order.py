@@ -36,9 +36,11 @@ def test_the_orders_that_the_measurements_chose_are_the_ones_planned(cases):
     assert by[("khi_m_heavy", 16384, 16384)]["squares"] == 256 and by[("khi_m_heavy", 16384, 16384)]["reversed"] == 8192
     assert by[("full", 4096, 4096)]["squares"] == 0 and by[("lower", 8192, 8192)]["squares"] == 0
     assert by[("lower_wtw", 16384, 16384)]["squares"] == 0          # K range depends on both indices
-    # LOWER from 32 tiles on: strictly-lower launch (whole rounds of 512) + diagonal band of 64-tiles
+    # LOWER from 32 tiles on: strictly-lower launch (whole rounds of 512) + diagonal band: ten 32-tiles per diagonal
+    # 128-block up to 64 blocks, three 64-tiles per block beyond
     c = by[("lower", 8192, 8192)]
-    assert c["band"] == 1 and c["tiles"] == 2016 and c["band_tiles"] == 192
+    assert c["band"] == 1 and c["tiles"] == 2016 and c["band_tiles"] == 640
+    assert by[("lower", 4096, 4096)]["band_tiles"] == 320 and by[("lower", 16384, 16384)]["band_tiles"] == 384
     assert by[("lower", 2048, 2048)]["band"] == 0 and by[("lower_noband", 8192, 8192)]["tiles"] == 2080
     # tall outputs: per-XCD rows for full products, squares one square wide for the triangular ones
     assert by[("tall_full", 1048576, 1024)]["xcd_rows"] == 1 and by[("tall_klo_n", 1048576, 1024)]["squares"] == 1024

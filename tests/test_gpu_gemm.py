@@ -93,8 +93,9 @@ def test_gemm_square_tile_order_all_forms(n):
 @pytest.mark.parametrize("order", ["plain", "squares"])
 def test_gemm_lower_strict_launch_plus_diagonal_band(n, order):
     """LOWER products of >= 32 tiles run as two launches: the tiles strictly below the diagonal, then the
-    diagonal 128 x 128 blocks as three 64 x 64 tiles each.  Together they must give every element of the
-    lower triangle, and nothing may be written 128 or more columns right of the diagonal."""
+    diagonal 128 x 128 blocks as ten 32 x 32 tiles each (up to 64 blocks) or three 64 x 64 tiles each (more
+    blocks, or GEMM_NO_TILE32).  Together they must give every element of the lower triangle, and nothing may be
+    written 128 or more columns right of the diagonal."""
     lib = _lib()
     K = 192
     rng = np.random.default_rng(n)
@@ -107,6 +108,9 @@ def test_gemm_lower_strict_launch_plus_diagonal_band(n, order):
     assert np.array_equal(np.triu(C, 128), np.triu(C0, 128))
     C1 = lib.dgemm(D, D, C0, alpha=-1.0, beta=1.0, flags=flags | lib.GEMM_NO_BAND)   # one launch, as before
     assert np.max(np.abs(np.tril(C1) - np.tril(ref))) <= 1e-13 * K
+    C2 = lib.dgemm(D, D, C0, alpha=-1.0, beta=1.0, flags=flags | lib.GEMM_NO_TILE32)   # the band of 64 x 64 tiles
+    assert np.max(np.abs(np.tril(C2) - np.tril(ref))) <= 1e-13 * K
+    assert np.array_equal(np.triu(C2, 128), np.triu(C0, 128))
 
 
 def test_gemm_splitk_tall():
