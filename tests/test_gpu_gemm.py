@@ -81,9 +81,17 @@ def test_gemm_square_tile_order_all_forms(n):
     # B(n,k) = L[n,k], k <= n (trip count grows with the N tile)
     C = lib.dgemm(D, L, flags=lib.GEMM_KHI_N | sq)
     assert np.max(np.abs(C - D @ L.T)) <= tol
+    # ... the K tiles of the diagonal 128-block cut at 64 (gemm_kernel<4,4,..,SK=1>) only leave out products with
+    # structural zeros: bit-identical to the launch that multiplies them (GEMM_NO_HALF_SKIP), both K directions
+    assert np.array_equal(C, lib.dgemm(D, L, flags=lib.GEMM_KHI_N | sq | lib.GEMM_NO_HALF_SKIP))
+    assert np.array_equal(lib.dgemm(D, L, flags=lib.GEMM_KHI_N | lib.GEMM_TILE128),
+                          lib.dgemm(D, L, flags=lib.GEMM_KHI_N | lib.GEMM_TILE128 | lib.GEMM_NO_HALF_SKIP))
     # B(n,k) = W[k][n], W lower: k >= n
     C = lib.dgemm(D, L.T.copy(), flags=lib.GEMM_KLO_N | sq, b_kc=True)
     assert np.max(np.abs(C - D @ L)) <= tol
+    assert np.array_equal(C, lib.dgemm(D, L.T.copy(), flags=lib.GEMM_KLO_N | sq | lib.GEMM_NO_HALF_SKIP, b_kc=True))   # SK = 2
+    assert np.array_equal(lib.dgemm(D, L.T.copy(), flags=lib.GEMM_KLO_N | lib.GEMM_TILE128, b_kc=True),
+                          lib.dgemm(D, L.T.copy(), flags=lib.GEMM_KLO_N | lib.GEMM_TILE128 | lib.GEMM_NO_HALF_SKIP, b_kc=True))
     # A(m,k) = W[k][m], W lower: k >= m
     C = lib.dgemm(L.T.copy(), E, flags=lib.GEMM_KLO_M | sq, a_kc=True)
     assert np.max(np.abs(C - L.T @ E.T)) <= tol
