@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (public spec)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md)
 METRIC = "NLL+grad evals/sec: exact GP n=65536 d=20; FITC n=1M m=1024; % fp64 peak"
-PMC_DIRS = ("r02_pmc", "r01_pmc")   # newest committed rocprofv3 --pmc summary first
+PMC_DIRS = ("r02d_pmc", "r02_pmc", "r01_pmc")   # newest committed rocprofv3 --pmc summary first
 
 
 # ---- launcher: --gpus N > 1 without an outer torchrun ------------------------------------------------
