@@ -359,6 +359,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         // tiles load as much as the full ones).  A third shape for the diagonal tiles of a LOWER product (all but rows
         // 0-63 x columns 64-127) made the split-K Gram products SLOWER, 17.7 -> 18.6 ms: the diagonal tiles run ahead of the
         // other tiles of their slab and fetch their operands from HBM a second time; not kept.
+        // RD == 2: the epilogue reads the 128 x 128 tile of E in four batches per wave, one L2-miss round trip each.
+        // With the loads of the LAST K tile, every thread touches four of the tile's 1024 lines (4-byte direct-to-LDS
+        // loads into the dummy word, as the operand warm-up), two K tiles before the epilogue needs them.
+        const char* pe = RD == 2 ? reinterpret_cast<const char*>(g.E) + ((long)m0 + (long)n0 * g.lde) * 8 : nullptr;
+        const unsigned eoff = (unsigned)(((tid & 7) * 16 + (long)(tid >> 3) * g.lde) * 8);   // 16-row chunk, column tid / 8
+        auto warm_e = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)   // columns 32 q + tid / 8
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(eoff), "s"(pe + q * 32 * g.lde * 8),
+                             "s"(wdst)
+                             : "memory", "m0");
+        };
         auto run = [&](auto SC) {
             constexpr bool scaled = decltype(SC)::value;
             auto issue = [&](int stage) {
@@ -412,8 +424,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                     issue(1);
                     const bool more = rem > 2;
                     if (more) warm();
+                    else if (RD == 2) warm_e();
                     multiply(0, MODE);
                     if (more) __builtin_amdgcn_s_waitcnt(0x0f71);
+                    else if (RD == 2) __builtin_amdgcn_s_waitcnt(0x0f74);   // vmcnt(4): the four touches of E stay in flight
                     else __builtin_amdgcn_s_waitcnt(0x0f70);
                     __syncthreads();
                     if (more) {
@@ -758,6 +772,7 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     const TilePlan plan = plan_tiles(M, N, flags, splitk, kscale != nullptr);
     static_cast<TileOrder&>(g) = plan.main;
     if (!gemm_lane_offsets_fit_32bit(lda, a_kc != 0) || !gemm_lane_offsets_fit_32bit(ldb, b_kc != 0)) g.flags |= GEMM_NO_FAST32;
+    if (g.E && !gemm_lane_offsets_fit_32bit(g.lde, true)) g.flags |= GEMM_NO_FAST32;   // the E warm-up offsets: 31 columns of lde
     const int bt = plan.bt;
     const bool band = plan.band;
     const long grid = plan.grid;
