@@ -66,8 +66,9 @@ int gpx_dgemm_kscale(int b_kc, int64_t M, int64_t N, int64_t K, double alpha, co
 int gpx_dgemm_rowdot(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
                      int64_t ldb, double* C, int64_t ldc, int flags, const double* E, int64_t lde, const double* evec,
                      double* R1, double* R2, int64_t ldr) {
-    if (!A || !B || !C || !R1 || M < 0 || N < 0 || K < 0) return GPX_ERR_ARG;
-    if (lda < M || ldb < N || ldc < M || ldr < M || (E && lde < M)) return GPX_ERR_ARG;
+    if (!A || !B || !C || M < 0 || N < 0 || K < 0) return GPX_ERR_ARG;
+    if (!R1 && !(evec && R2 && !E)) return GPX_ERR_ARG;   // R1 == NULL: the operand dot R2 = A evec
+    if (lda < M || ldb < N || ldc < M || (R1 && ldr < M) || (E && lde < M)) return GPX_ERR_ARG;
     GemmRowdot rd = {E, lde, evec, R1, R2, ldr};
     return gpx_gemm_rowdot(0, 0, 0, M, N, K, alpha, A, lda, B, ldb, C, ldc, flags, rd);
 }

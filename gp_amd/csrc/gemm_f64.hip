@@ -41,6 +41,8 @@ struct GemmArgs : TileOrder {
     //   R1[p*ldr + m] = sum_{n in part} C(m,n) * E(m,n)   (E == nullptr: E = C, i.e. row sums of squares)
     //   R2[p*ldr + m] = sum_{n in part} E(m,n) * evec[n]   (when E and evec are given)
     // so that the row statistics of a tall-skinny product do not cost a pass of their own over it
+    // or the operand dot (RD == 3: E == R1 == nullptr): R2[m] = sum_k A(m,k) * evec[k], formed from the A fragments of the
+    // tiles of the first tile column on their way to the MFMAs (Kxu * a of VFE.cpp:176 without a pass over Kxu)
     const double* E; long lde;
     const double* evec;
     double* R1; double* R2; long ldr;
@@ -279,6 +281,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[j][i] = (v4d){0.0, 0.0, 0.0, 0.0};
 
+    double sv[TM];   // RD == 3, tiles of the first tile column: this lane's share of sum_k A(m0 + wm + 16 i + l15, k) evec[k]
+#pragma unroll
+    for (int i = 0; i < TM; ++i) sv[i] = 0.0;
+    bool dot_done = false;
     const bool tfA = g.fastA && (m0 + BM <= g.M);
     const bool tfB = g.fastB && (n0 + BN <= g.N);
     v2d ra[NLA], rb[NLB];
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         // beside the operand tiles (wave 0: one 4-byte load per lane, the upper 32 lanes write a second
         // copy) and multiply the A fragments on their way to the MFMAs.
         __shared__ __attribute__((aligned(16))) double sks[2][32];
-        const char* ps = reinterpret_cast<const char*>(g.kscale) + k00 * 8;
+        const char* ps = reinterpret_cast<const char*>(RD == 3 ? g.evec : g.kscale) + k00 * 8;
         const long ksd = down ? -(long)BK * 8 : (long)BK * 8;
         const unsigned soff = (unsigned)((lane & 31) * 4);
         // Half-tile skipping (see sub16; SK != 0 instantiations, chosen by the host from the flags).  A K tile of a
@@ -371,8 +377,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                              "s"(wdst)
                              : "memory", "m0");
         };
-        auto run = [&](auto SC) {
+        auto run = [&](auto SC, auto DOT) {
             constexpr bool scaled = decltype(SC)::value;
+            constexpr bool dot = decltype(DOT)::value;   // the vector of this K tile travels like the K scale
             auto issue = [&](int stage) {
                 double* st = stage ? smem1 : smem;
                 const unsigned dA = lds_addr(st + wv * QA), dB = lds_addr(st + LA + wv * QB);
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 for (int i = 0; i < 4; ++i) dlds16(pa + i * ia, ta, dA + 4 * i * QA * 8);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dlds16(pb + i * ib, tb, dB + 4 * i * QB * 8);
-                if (scaled) {
+                if (scaled || dot) {
                     if (wv == 0)
                         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(soff), "s"(ps),
                                      "s"(lds_addr(sks[stage]))
@@ -406,6 +413,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                         const double sc = sks[stage][kk * 4 + l4];
 #pragma unroll
                         for (int i = 0; i < TM; ++i) fa[i] *= sc;
+                    }
+                    if (dot) {
+                        const double ek = sks[stage][kk * 4 + l4];
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) sv[i] = fma(fa[i], ek, sv[i]);
                     }
 #pragma unroll
                     for (int j = J0; j < J1; ++j)
@@ -460,8 +472,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             segment(std::integral_constant<int, 0>{}, rem - n_last);   // rem: n_first is done
             if (SK != 0) segment(HALF{}, n_last);
         };
-        if (AKC && g.kscale != nullptr) run(std::true_type{});
-        else run(std::false_type{});
+        if (RD == 3 && bj == 0) {
+            run(std::false_type{}, std::true_type{});
+            dot_done = true;
+        } else if (AKC && g.kscale != nullptr) {
+            run(std::true_type{}, std::false_type{});
+        } else {
+            run(std::false_type{}, std::false_type{});
+        }
     } else if (interior && TM <= 2 && TN <= 2) {
         // 64x64 tiles: the products of the factorisation chains below 2048 rows, a few tiles on a few CUs with nothing
         // co-resident to hide a load behind.  One K step of MFMAs is 0.43 us, an L2 / HBM load takes longer, so the
@@ -638,6 +656,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     // epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4) + 4r]
     double* Cb = g.C + (g.splitk > 1 ? (long)ks * g.slab : 0);
     const bool plain = RD != 0 || g.splitk > 1 || g.beta == 0.0;   // the row-dot variants are beta == 0 only: no old-value path in them
+    if (RD == 3 && bj == 0) {
+        if (dot_done) {   // the two waves of a row half hold the same sums: one of them writes
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                double a = sv[i];
+                a += __shfl_xor(a, 16, 64);
+                a += __shfl_xor(a, 32, 64);
+                if (l4 == 0 && (wave >> 1) == 0) g.R2[m0 + wm + 16 * i + l15] = a;
+            }
+        } else {   // edge tiles and launches outside the direct-to-LDS loop: one row per thread, straight from memory
+            const int m = m0 + tid;
+            if (tid < BM && m < g.M) {
+                double a = 0.0;
+                for (int k = 0; k < g.K; ++k) a = fma(AKC ? g.A[k + (long)m * g.lda] : g.A[m + (long)k * g.lda], g.evec[k], a);
+                g.R2[m] = a;
+            }
+        }
+    }
     const int part = 2 * bj + (wave >> 1);   // row-dot parts: two per tile column (one per wave column)
     if (RD == 2 && m0 + BM <= g.M && n0 + BN <= g.N) {
         store_rowdot_full<TM, TN>(g, acc, Cb, m0 + wm, n0 + wn, part, l15, l4);
@@ -668,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                     for (int i = 0; i < TM; ++i) cj[r * s4 + 16 * i] = g.alpha * acc[j][i][r] + g.beta * old[r][i];
             }
         }
-        if (RD) rowdot_epilogue<TM, TN, true, RD>(g, acc, m0 + wm, n0 + wn, part, l15, l4);
+        if (RD == 1 || RD == 2) rowdot_epilogue<TM, TN, true, RD>(g, acc, m0 + wm, n0 + wn, part, l15, l4);
         return;
     }
 #pragma unroll
@@ -686,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 }
             }
         }
-    if (RD) rowdot_epilogue<TM, TN, false, RD>(g, acc, m0 + wm, n0 + wn, part, l15, l4);   // a part without columns gets zeros
+    if (RD == 1 || RD == 2) rowdot_epilogue<TM, TN, false, RD>(g, acc, m0 + wm, n0 + wn, part, l15, l4);   // a part without columns gets zeros
 }
 
 __global__ void splitk_reduce_kernel(double* __restrict__ C, long ldc, const double* __restrict__ W,
@@ -748,6 +784,14 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
               const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
               int flags, int splitk, double* work, const double* kscale = nullptr, const GemmRowdot* rd = nullptr) {
     if (M <= 0 || N <= 0) return GPX_OK;
+    const bool opdot = rd && !rd->R1 && !rd->E && rd->evec && rd->R2;   // R2 = A evec from the operand fragments
+    if (opdot) {
+        if (a_kc || b_kc || beta != 0.0 || splitk > 1 || (flags & (GEMM_LOWER | GEMM_TILE64 | GEMM_KLO_M | GEMM_KHI_M | GEMM_KLO_N | GEMM_KHI_N))) return GPX_ERR_ARG;
+        if (reinterpret_cast<uintptr_t>(rd->evec) & 3) return GPX_ERR_ARG;
+        flags |= GEMM_TILE128;
+    } else if (rd && !rd->R1) {
+        return GPX_ERR_ARG;
+    }
     if (rd && rd->R1) {
         if (a_kc || b_kc || beta != 0.0 || splitk > 1 || (flags & (GEMM_LOWER | GEMM_TILE64)) || (rd->E && !(rd->evec && rd->R2)) || (!rd->E && (rd->evec || rd->R2))) return GPX_ERR_ARG;
         flags |= GEMM_TILE128;   // the parts are the columns one wave of a 128-tile owns
@@ -764,7 +808,7 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     g.alpha = alpha; g.beta = beta;
     g.kscale = kscale;
     g.E = nullptr; g.lde = 0; g.evec = nullptr; g.R1 = g.R2 = nullptr; g.ldr = 0;
-    if (rd && rd->R1) {
+    if (rd && (rd->R1 || opdot)) {
         g.E = rd->E; g.lde = rd->lde; g.evec = rd->evec; g.R1 = rd->R1; g.R2 = rd->R2; g.ldr = rd->ldr;
     }
     g.fastA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 2 == 0);
@@ -800,7 +844,8 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
         }
     }
     const int sk = bt == 128 ? half_skip_kind(flags) : 0;
-    if (g.R1 && g.E) hipLaunchKernelGGL((gemm_kernel<4, 4, false, false, 2>), dim3((unsigned)grid), dim3(256), 0, st, g);
+    if (opdot) hipLaunchKernelGGL((gemm_kernel<4, 4, false, false, 3>), dim3((unsigned)grid), dim3(256), 0, st, g);
+    else if (g.R1 && g.E) hipLaunchKernelGGL((gemm_kernel<4, 4, false, false, 2>), dim3((unsigned)grid), dim3(256), 0, st, g);
     else if (g.R1 && sk == 1) hipLaunchKernelGGL((gemm_kernel<4, 4, false, false, 1, 1>), dim3((unsigned)grid), dim3(256), 0, st, g);
     else if (g.R1) hipLaunchKernelGGL((gemm_kernel<4, 4, false, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, g);
     else if (bt == 128 && sk == 1) launch<4, 4, 1>(st, a_kc, b_kc, g, (int)grid);

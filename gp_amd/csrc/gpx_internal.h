@@ -57,6 +57,7 @@ int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, 
 //   R1[p*ldr + m] = sum_{n in part p} C(m,n) * E(m,n)     (E == NULL: E = C, the row sums of squares)
 //   R2[p*ldr + m] = sum_{n in part p} E(m,n) * evec[n]    (E, evec and R2 come together or not at all)
 // (2*ceil(N/128) parts, column n in part 2*(n/128) + (n%64)/32; ldr >= M; every part of every row m < M is written, deterministically)
+// Operand dot (E == R1 == nullptr, evec with K entries, R2 with M entries): R2[m] = sum_k A(m,k) evec[k], from the A fragments.
 struct GemmRowdot {
     const double* E; long lde;
     const double* evec;

@@ -463,7 +463,6 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
 
     // ---- phase 3 ------------------------------------------------------------------------------
     if ((rc = s.gram(c->Winv_A.p, c->A_inv.p))) return rc;
-    if (!fitc && (rc = gpx_gemv_n(st, n, m, 1.0, c->Kxu.p, ldn, a_vec, 0.0, Ka))) return rc;  // Kxu a (FITC: inside fitc_rowstats)
     TraceArgs ta = {};
     ta.Xt1 = c->Xt.p; ta.ld1 = c->ldx; ta.p = n;
     ta.Xt2 = c->Ut.p; ta.ld2 = c->ldu; ta.q = m;
@@ -503,7 +502,11 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         hipLaunchKernelGGL(mm_combine_full_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, 1.0, c->A_inv.p, ldm,
                            -1.0 / h.sn2, c->Kuu_inv.p, ldm, 0.0, (const double*)nullptr, 0.0, (const double*)nullptr, 0L,
                            c->Wuu.p, ldm);
-        if ((rc = gpx_gemm(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->Wuu.p, ldm, 0.0, c->Cm.p, ldn, 0))) return rc;
+        // Kxu a (VFE.cpp:176) leaves this product with Kxu P: the operand dot of the GEMM, no pass of its own over Kxu
+        // (the GEMV took 13 ms of 841 at n = 2^22, m = 2048)
+        GemmRowdot rd = {};
+        rd.evec = a_vec; rd.R2 = Ka;
+        if ((rc = gpx_gemm_rowdot(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->Wuu.p, ldm, c->Cm.p, ldn, 0, rd))) return rc;
         double* nalpha = c->vn[3].p;
         hipLaunchKernelGGL(vfe_alpha_kernel, dim3(nblk(n)), dim3(256), 0, st, n, c->r.p, Ka, h.sn2, nalpha, s.part());
         s.finish_partials(n, redT + GPX_MAX_DIM + 8, 2);  // sum alpha^2, sum alpha

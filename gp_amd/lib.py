@@ -143,6 +143,20 @@ def dgemm_rowdot(A, B, E=None, evec=None, alpha=1.0, flags=0):
     return Cm, dR1.to_numpy((parts, M)), (dR2.to_numpy((parts, M)) if dR2 else None)
 
 
+def dgemm_opdot(A, B, evec, alpha=1.0, flags=0):
+    """Test helper: C = alpha*A@B.T together with the operand dot R2 = A @ evec (gpx_dgemm_rowdot with R1 = E = NULL)."""
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    M, K = A.shape
+    N = B.shape[0]
+    dA, dB = DeviceBuffer.from_numpy(colmajor(A)), DeviceBuffer.from_numpy(colmajor(B))
+    dC, dR2 = DeviceBuffer(M * N), DeviceBuffer(M)
+    dv = DeviceBuffer.from_numpy(np.asarray(evec, dtype=np.float64))
+    check(lib.gpx_dgemm_rowdot(M, N, K, alpha, dA.ptr, M, dB.ptr, N, dC.ptr, M, flags, None, 0, dv.ptr, None, dR2.ptr, 0),
+          "dgemm_rowdot (operand dot)")
+    return dC.to_numpy().reshape(N, M).T.copy(), dR2.to_numpy()
+
+
 # ---- high-level API ---------------------------------------------------------------------------
 MODEL_EXACT, MODEL_FITC, MODEL_VFE = 0, 1, 2
 COV_SE_ARD, COV_SE_ISO = 0, 1

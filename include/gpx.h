@@ -45,7 +45,11 @@ int gpx_dgemm_kscale(int b_kc, int64_t M, int64_t N, int64_t K, double alpha, co
  *   R1[p*ldr + m] = sum_{n in part p} C(m,n) * E(m,n)     (E == NULL: E = C, row sums of squares)
  *   R2[p*ldr + m] = sum_{n in part p} E(m,n) * evec[n]    (E, evec, R2 all given or all NULL)
  * Replaces the separate passes diag(Kxu Kuu^-1 Kux) = rowsum(V o V) (FITC.cpp:215), rowsum(C o Kxu) and Kxu * a
- * (FITC.cpp:219-220, 262-263): the statistics leave the GEMM that forms V / C in its epilogue. */
+ * (FITC.cpp:219-220, 262-263): the statistics leave the GEMM that forms V / C in its epilogue.
+ * Operand dot (E == NULL, R1 == NULL, evec (K entries) and R2 (M entries) given; full K range, no triangular flags):
+ *   R2[m] = sum_k A(m,k) * evec[k]
+ * formed from the fragments of A on their way to the matrix cores: Kxu * a of VFE.cpp:176 (alpha = (r - Kxu a)/sn2)
+ * without a pass of its own over Kxu, inside the product Kxu * P of VFE.cpp:205-209. */
 int gpx_dgemm_rowdot(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
                      int64_t ldb, double* C, int64_t ldc, int flags, const double* E, int64_t lde, const double* evec,
                      double* R1, double* R2, int64_t ldr);

@@ -201,6 +201,21 @@ def test_gemm_rowdot_epilogue_ragged_shapes(shape, with_e):
         assert np.max(np.abs(R1.sum(axis=0) - np.sum(ref * ref, axis=1))) <= 1e-11 * np.max(np.sum(ref * ref, axis=1)) * K
 
 
+@pytest.mark.parametrize("shape", [(256, 128, 64), (1000, 200, 96), (130, 65, 20), (8192, 2048, 2048), (517, 1, 33)])
+def test_gemm_operand_dot_from_the_fragments(shape):
+    """R2 = A evec (Kxu a of VFE.cpp:176) leaves the GEMM Kxu P of VFE.cpp:205-209: from the A fragments of the first
+    tile column in the direct-to-LDS loop (full tiles), straight from memory for edge tiles; against NumPy."""
+    lib = _lib()
+    M, N, K = shape
+    rng = np.random.default_rng(M + 3 * N + K)
+    A, B, v = rng.standard_normal((M, K)), rng.standard_normal((N, K)), rng.standard_normal(K)
+    C, R2 = lib.dgemm_opdot(A, B, v, alpha=0.7)
+    ref = 0.7 * A @ B.T
+    assert np.max(np.abs(C - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))) * K
+    r2 = A @ v
+    assert R2.shape == (M,) and np.max(np.abs(R2 - r2)) <= 1e-13 * max(1.0, np.max(np.abs(r2))) * K
+
+
 @pytest.mark.parametrize("layout", [(False, False), (False, True), (True, False), (True, True)])
 def test_gemm_32_tiles_for_products_of_few_tiles(layout):
     """Products of at most 64 tiles of 64x64 take 32x32 tiles (gemm_kernel<1,1,..>, the chains below 1024 rows): every
