@@ -398,6 +398,10 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, c->r.p, 0.0, redF))) return rc;  // F = Kux r
     }
     // S = Kux [Gamma^-1] Kxu, lower tiles, split-K over the training rows (FITC.cpp:217, VFE.cpp:173)
+    // (F = Kux [Gamma^-1] r as an operand dot of THIS product - from the A fragments of its first tile column, partial sums
+    // per split-K slab, as Kxu a leaves the product Kxu P below - was written and measured: the tiles that carry the dot
+    // fall behind the other tiles of their slab and the slab loses its shared L2 reads; the Gram product grows by more
+    // than the GEMV it replaces, FITC 113.25 -> 113.6 ms, VFE 846 -> 866 ms, same box; not kept.)
     if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Kxu.p, ldn, c->Kxu.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
                               fitc ? g : nullptr)))
         return rc;
