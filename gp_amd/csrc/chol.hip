@@ -209,6 +209,8 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {   // lane: 
 
 __device__ __forceinline__ v4d mfma16(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
+// XP = true (GPX_EXACT_PIVOT=1, A/B): correctly rounded pivots, l_jj = sqrt(d), column divided by l_jj, 1 / l_jj by division
+template <bool XP>
 __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict__ A, long lda, int nb, double* __restrict__ W,
                                                              long ldw, int* __restrict__ info) {
     __shared__ __align__(16) double S[NBI * LDI];
@@ -245,11 +247,18 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
             // 1/sqrt(d) on the critical path of the whole block: hardware estimate t0 (>= 26 bits), then ONE third-order
             // step t0 (1 + e/2 + 3 e^2/8), e = 1 - d t0^2 (error ~ e^3: full precision, two dependent operations less
             // than two Newton steps)
-            double t = __builtin_amdgcn_rsq(d);
-            const double er = fma(-d * t, t, 1.0);
-            t = fma(t * er, fma(0.375, er, 0.5), t);
+            double t, lij;
+            if (XP) {
+                const double l = sqrt(d);
+                t = 1.0 / l;
+                lij = (l15 == j) ? l : r[j] / l;
+            } else {
+                t = __builtin_amdgcn_rsq(d);
+                const double er = fma(-d * t, t, 1.0);
+                t = fma(t * er, fma(0.375, er, 0.5), t);
+                lij = r[j] * t;                             // column j of L (lane j: sqrt(d))
+            }
             if (l15 == j) tl = t;
-            const double lij = r[j] * t;                    // column j of L (lane j: sqrt(d))
             r[j] = lij;
 #pragma unroll
             for (int c = j + 1; c < 16; ++c) r[c] = fma(-lij, readlane_f64(lij, c), r[c]);
@@ -286,7 +295,8 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
                 for (int c = 0; c < 16; ++c) x[c] = S[row + (o + c) * LDI];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    x[j] *= invd[o + j];
+                    if (XP) x[j] /= S[(o + j) + (o + j) * LDI];
+                    else x[j] *= invd[o + j];
 #pragma unroll
                     for (int c = j + 1; c < 16; ++c) x[c] = fma(-x[j], S[(o + c) + (o + j) * LDI], x[c]);
                 }
@@ -532,6 +542,7 @@ inline long inv_split(long n) { return ((n / 2 + NBI - 1) / NBI) * NBI; }
 // side product holds every CU until it ends, equal or low stream priority alike, so the chain of small launches
 // it was meant to hide waits behind it: exact n = 8192 17.1 -> 23.2 ms.)
 bool g_base64 = false;   // GPX_BASE64=1: the 64-row scalar base block and its split (A/B measurements)
+bool g_exact_pivot = false;   // GPX_EXACT_PIVOT=1: correctly rounded pivots in the 128-row base block (A/B measurements)
 
 int potrf_inv_rec(hipStream_t st, long n, double* A, long lda, double* W, long ldw, double* T, int* info) {
     if (g_base64 && n <= NB) {
@@ -539,7 +550,8 @@ int potrf_inv_rec(hipStream_t st, long n, double* A, long lda, double* W, long l
         return GPX_OK;
     }
     if (!g_base64 && n <= NBI) {
-        hipLaunchKernelGGL(potrf_inv_base_kernel, dim3(1), dim3(512), 0, st, A, lda, (int)n, W, ldw, info);
+        if (g_exact_pivot) hipLaunchKernelGGL(potrf_inv_base_kernel<true>, dim3(1), dim3(512), 0, st, A, lda, (int)n, W, ldw, info);
+        else hipLaunchKernelGGL(potrf_inv_base_kernel<false>, dim3(1), dim3(512), 0, st, A, lda, (int)n, W, ldw, info);
         return GPX_OK;
     }
     const long n1 = g_base64 ? split(n) : inv_split(n), n2 = n - n1;
@@ -597,7 +609,13 @@ int gpx_potrf(hipStream_t st, long n, double* A, long lda, double* Wd, int* info
 
 int gpx_potrf_inv(hipStream_t st, long n, double* A, long lda, double* W, long ldw, double* T, int* info) {
     if (n <= 0) return GPX_OK;
-    static const bool init = [] { const char* e = getenv("GPX_BASE64"); g_base64 = e && e[0] == '1'; return true; }();
+    static const bool init = [] {
+        const char* e = getenv("GPX_BASE64");
+        g_base64 = e && e[0] == '1';
+        e = getenv("GPX_EXACT_PIVOT");
+        g_exact_pivot = e && e[0] == '1';
+        return true;
+    }();
     (void)init;
     const int rc = potrf_inv_rec(st, n, A, lda, W, ldw, T, info);
     if (rc) return rc;

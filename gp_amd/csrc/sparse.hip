@@ -12,6 +12,7 @@
 // The per-hyper loops of the reference (FITC.cpp:269-308, VFE.cpp:213-237), which materialise
 // dKxu and an n x m x m product PER HYPER, become one pass that is independent of d.
 #include "ctx.h"
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -381,6 +382,18 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     *nll = INF;
     if (calc_grad) memset(grad, 0, sizeof(double) * nh);  // FITC.cpp:232 / VFE.cpp:194 on failure
 
+    // FITC in WHITENED form.  The reference forms A = sn2 Kuu + Kux Gamma^-1 Kxu (FITC.cpp:217), whose condition number
+    // at the benchmark's own conditions is 1.2e9: the data-fit term F^T A^-1 F / sn2 then carries ~3e-9 of rounding from
+    // nothing but A's own fp64 entries (an 80-bit A rounded to fp64 and factored by LAPACK is 5.6e-9 off in F^T A^-1 F,
+    // tools/study_fitc_terms.py), which is 1e-9 of the NLL.  With V = Kxu Lu^-T (already formed for Gamma):
+    //     A = Lu M Lu^T,   M = sn2 I + V^T Gamma^-1 V            (cond 2e4)
+    //     F^T A^-1 F = F_v^T M^-1 F_v,  F_v = V^T Gamma^-1 r;    log|A| - log|Kuu| = log|M|  (no cancellation)
+    //     a = A^-1 F = Lu^-T M^-1 F_v;  A^-1 = (W_M W_u)^T (W_M W_u)   with W_M = L_M^-1, W_u = Lu^-1
+    // Same flops (the Gram product and the GEMV read V instead of Kxu), one extra m x m triangular product for the
+    // gradient; the all-reduced partials are [F_v | V^T Gamma^-1 V] instead of [F | S].  GPX_FITC_NO_WHITEN=1 keeps the
+    // reference's A (A/B runs).
+    const bool wh = fitc && c->fitc_whiten;
+    const double* gram_op = wh ? c->V.p : c->Kxu.p;
     // ---- phase 1 ------------------------------------------------------------------------------
     if ((rc = s.kernels(jitter, true, true))) return rc;  // Lu diag + Winv_u = Lu^-1
     HIP_TRY(hipMemsetAsync(redT, 0, 16 * sizeof(double), st));
@@ -391,7 +404,8 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         s.finish_partials(n, redT, 3);  // sum log Gamma, r^T Gamma^-1 r, n_local
         // (this HBM-bound GEMV on the side stream, beside the matrix-pipe-bound Gram product below, was measured: the Gram
         // product loses more than the GEMV's 1.65 ms, 113.4 -> 114.9 ms per evaluation)
-        if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, p, 0.0, redF))) return rc;  // F = Kux Gamma^-1 r
+        // whitened form (default): F_v = V^T Gamma^-1 r = Lu^-1 F;  else F = Kux Gamma^-1 r (FITC.cpp:218)
+        if ((rc = gpx_gemv_t(st, n, m, 1.0, gram_op, ldn, p, 0.0, redF))) return rc;
     } else {
         hipLaunchKernelGGL(vfe_rstats_kernel, dim3(nblk(n)), dim3(256), 0, st, n, c->r.p, s.part());
         s.finish_partials(n, redT, 3);  // r^T r, -, n_local
@@ -402,7 +416,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     // per split-K slab, as Kxu a leaves the product Kxu P below - was written and measured: the tiles that carry the dot
     // fall behind the other tiles of their slab and the slab loses its shared L2 reads; the Gram product grows by more
     // than the GEMV it replaces, FITC 113.25 -> 113.6 ms, VFE 846 -> 866 ms, same box; not kept.)
-    if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Kxu.p, ldn, c->Kxu.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
+    if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, gram_op, ldn, gram_op, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
                               fitc ? g : nullptr)))
         return rc;
     HIP_TRY(hipEventRecord(c->ev[0], st));
@@ -419,17 +433,26 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     st = c->st2;
     s.st = st;
     HIP_TRY(hipStreamWaitEvent(st, c->ev[0], 0));
-    hipLaunchKernelGGL(mm_combine_lower_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, h.sn2, c->Kuu.p, ldm, 1.0, red, m,
-                       0.0, c->Am.p, ldm);
+    if (wh)   // M = sn2 I + V^T Gamma^-1 V
+        hipLaunchKernelGGL(mm_combine_lower_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, 0.0, c->Kuu.p, ldm, 1.0, red, m,
+                           h.sn2, c->Am.p, ldm);
+    else
+        hipLaunchKernelGGL(mm_combine_lower_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, h.sn2, c->Kuu.p, ldm, 1.0, red, m,
+                           0.0, c->Am.p, ldm);
     HIP_TRY(hipMemcpyAsync(c->LA.p, c->Am.p, (size_t)ldm * m * sizeof(double), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemsetAsync(c->Winv_A.p, 0, (size_t)ldm * m * sizeof(double), st));
     if ((rc = gpx_potrf_inv(st, m, c->LA.p, ldm, c->Winv_A.p, ldm, c->T.p, c->info + 1))) return rc;
-    // a = A^-1 F = W_A^T (W_A F)
+    // z = W_A F (whitened: W_M F_v);  F^T A^-1 F = z^T z;  a = A^-1 F = W_A^T z (whitened: W_u^T W_M^T z)
     if ((rc = gpx_gemv_n(st, m, m, 1.0, c->Winv_A.p, ldm, redF, 0.0, c->vm[1].p, 1))) return rc;
-    if ((rc = gpx_gemv_t(st, m, m, 1.0, c->Winv_A.p, ldm, c->vm[1].p, 0.0, a_vec, 1))) return rc;
+    if (wh) {
+        if ((rc = gpx_gemv_t(st, m, m, 1.0, c->Winv_A.p, ldm, c->vm[1].p, 0.0, c->vm[2].p, 1))) return rc;
+        if ((rc = gpx_gemv_t(st, m, m, 1.0, c->Winv_u.p, ldm, c->vm[2].p, 0.0, a_vec, 1))) return rc;
+    } else if ((rc = gpx_gemv_t(st, m, m, 1.0, c->Winv_A.p, ldm, c->vm[1].p, 0.0, a_vec, 1))) {
+        return rc;
+    }
     if ((rc = gpx_logdiag_sum(st, m, c->Lu.p, ldm, c->scal.p + S_LDU))) return rc;
     if ((rc = gpx_logdiag_sum(st, m, c->LA.p, ldm, c->scal.p + S_LDA))) return rc;
-    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, st, m, redF, a_vec, c->scal.p + S_FA);
+    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, st, m, c->vm[1].p, c->vm[1].p, c->scal.p + S_FA);
     if (!fitc) {
         // VFE needs Kuu^-1 for the trace term already in the NLL (VFE.cpp:181,188)
         hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, red, m);
@@ -446,8 +469,14 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     int info[2];
     memcpy(info, hs + 16, sizeof(info));
     const double ntot = hs[8 + 2];
-    const double ldU = 2 * hs[S_LDU], ldA = 2 * hs[S_LDA], Fa = hs[S_FA];
+    const double ldU = wh ? 0.0 : 2 * hs[S_LDU], ldA = 2 * hs[S_LDA], Fa = hs[S_FA];   // whitened: ldA = log|M| = log|A| - log|Kuu|
     double v, f_tr = 0.0;
+    {
+        static const bool dbg = getenv("GPX_DEBUG_TERMS") != nullptr;   // the terms of the NLL, for tools/study_fitc_terms.py
+        if (dbg)
+            fprintf(stderr, "gpx terms: ldA %.17g ldU %.17g slg_or_rr %.17g rGr %.17g Fa %.17g whitened %d\n", 2 * hs[S_LDA],
+                    2 * hs[S_LDU], hs[8 + 0], hs[8 + 1], Fa, (int)wh);
+    }
     if (fitc) {
         const double data_fit = (hs[8 + 1] - Fa) / h.sn2;                                   // FITC.cpp:221-223
         const double mc = ldA - ldU + hs[8 + 0] + (ntot - (double)m) * log(h.sn2);           // FITC.cpp:226
@@ -466,7 +495,13 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     if (!calc_grad) return GPX_OK;
 
     // ---- phase 3 ------------------------------------------------------------------------------
-    if ((rc = s.gram(c->Winv_A.p, c->A_inv.p))) return rc;
+    if (wh) {
+        // W_A = W_M W_u (lower x lower; B(n,k) = W_u[k + n ldm] is zero for k < n), A^-1 = W_A^T W_A
+        if ((rc = gpx_gemm(st, 0, 1, m, m, m, 1.0, c->Winv_A.p, ldm, c->Winv_u.p, ldm, 0.0, c->Am.p, ldm, GEMM_KLO_N))) return rc;
+        if ((rc = s.gram(c->Am.p, c->A_inv.p))) return rc;
+    } else if ((rc = s.gram(c->Winv_A.p, c->A_inv.p))) {
+        return rc;
+    }
     TraceArgs ta = {};
     ta.Xt1 = c->Xt.p; ta.ld1 = c->ldx; ta.p = n;
     ta.Xt2 = c->Ut.p; ta.ld2 = c->ldu; ta.q = m;

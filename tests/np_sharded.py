@@ -32,22 +32,30 @@ def sparse_nll_grad_sharded(model, cov, X, y, U, jitter, hyp, allreduce):
         g_ = 1.0 / Gam
         p = g_ * r
         Ksc = g_[:, None] * K
-        buf = np.concatenate([(Ksc.T @ K).ravel(), K.T @ p, [np.log(Gam).sum(), r @ p, n_loc]])
+        # whitened partials (sparse.hip): V^T Gamma^-1 V and F_v = V^T Gamma^-1 r
+        buf = np.concatenate([(V.T @ (g_[:, None] * V)).ravel(), V.T @ p, [np.log(Gam).sum(), r @ p, n_loc]])
     else:
         buf = np.concatenate([(K.T @ K).ravel(), K.T @ r, [r @ r, 0.0, n_loc]])
     allreduce(buf)
     S, F, tail = buf[:m * m].reshape(m, m), buf[m * m:m * m + m], buf[m * m + m:]
     n = tail[2]
     # ---- phase 2 (replicated) -------------------------------------------------------------------
-    A = sn2 * Kuu + S
-    LA = np.linalg.cholesky(A)
-    a = cho_solve((LA, True), F)
-    ldA, ldU = 2 * np.log(np.diag(LA)).sum(), 2 * np.log(np.diag(Lu)).sum()
-    Ainv = cho_solve((LA, True), np.eye(m))
     Kuuinv = cho_solve((Lu, True), np.eye(m))
     if fitc:
-        nll = 0.5 * ((tail[1] - F @ a) / sn2 + ldA - ldU + tail[0] + (n - m) * np.log(sn2) + n * np.log(2 * np.pi))
+        # M = sn2 I + V^T Gamma^-1 V;  A = Lu M Lu^T, so log|A| - log|Kuu| = log|M|, F^T A^-1 F = |L_M^-1 F_v|^2,
+        # a = Lu^-T M^-1 F_v and A^-1 = (L_M^-1 Lu^-1)^T (L_M^-1 Lu^-1)
+        LM = np.linalg.cholesky(sn2 * np.eye(m) + S)
+        z = solve_triangular(LM, F, lower=True)
+        a = solve_triangular(Lu, solve_triangular(LM, z, lower=True, trans="T"), lower=True, trans="T")
+        WA = solve_triangular(LM, np.linalg.inv(Lu), lower=True)
+        Ainv = WA.T @ WA
+        nll = 0.5 * ((tail[1] - z @ z) / sn2 + 2 * np.log(np.diag(LM)).sum() + tail[0] + (n - m) * np.log(sn2) + n * np.log(2 * np.pi))
     else:
+        A = sn2 * Kuu + S
+        LA = np.linalg.cholesky(A)
+        a = cho_solve((LA, True), F)
+        ldA, ldU = 2 * np.log(np.diag(LA)).sum(), 2 * np.log(np.diag(Lu)).sum()
+        Ainv = cho_solve((LA, True), np.eye(m))
         f_tr = 0.5 * (n * sf2 - np.sum(Kuuinv * S)) / sn2
         nll = 0.5 * n * np.log(2 * np.pi) + 0.5 * (ldA - ldU + (n - m) * np.log(sn2)) + 0.5 * (tail[0] - F @ a) / sn2 + f_tr
     # ---- phase 3 (row-local) + all-reduce #2 ------------------------------------------------------

