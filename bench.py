@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (public spec)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E (MI355X_MICROARCH.md)
 METRIC = "NLL+grad evals/sec: exact GP n=65536 d=20; FITC n=1M m=1024; % fp64 peak"
-PMC_DIRS = ("r02d_pmc", "r02_pmc", "r01_pmc")   # newest committed rocprofv3 --pmc summary first
+PMC_DIRS = ("r03_pmc", "r02d_pmc", "r02_pmc", "r01_pmc")   # newest committed rocprofv3 --pmc summary first
 
 
 # ---- launcher: --gpus N > 1 without an outer torchrun ------------------------------------------------
@@ -50,7 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="default", choices=["default", "exact", "exact8192", "fitc", "vfe", "all"])
+    ap.add_argument("--workload", default="default", choices=["default", "exact", "exact8192", "fitc", "vfe", "config0", "all"])
     ap.add_argument("--n", type=int, default=65536)
     ap.add_argument("--d", type=int, default=20)
     ap.add_argument("--fitc-n", type=int, default=1 << 20)
@@ -59,6 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--vfe-m", type=int, default=2048)
     ap.add_argument("--vfe-d", type=int, default=50)
     ap.add_argument("--sparse-steps", type=int, default=5)
+    ap.add_argument("--vfe-steps", type=int, default=3, help="timed evaluations of the VFE leg (0.85 s each at n = 2^22)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--predict-t", type=int, default=4096, help="test points of the exact-GP predict timing (0: skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -146,6 +147,10 @@ def cpu_baseline(d, n_target, fitc_n, fitc_m):
 
     one = {n: t_exact(oracle.exact_nll, n) for n in (1024, 2048, 3072)}          # ~1 + 5 + 16 s
     a1 = _fit_power(list(one), list(one.values()), 3)
+    # the exponent the measured points themselves follow (log-log least squares): above 3 = the scalar port falling out
+    # of cache as n grows, i.e. the a*n^3 extrapolation UNDER-states the port's time at n = 65536 and says nothing
+    # about an Eigen build
+    p1 = float(np.polyfit(np.log(list(one)), np.log(list(one.values())), 1)[0])
     allc = {n: t_exact(oracle.exact_nll_all_cores, n) for n in (2048, 4096)}
     aN = _fit_power(list(allc), list(allc.values()), 3)
     out = {"value": 1.0 / (a1 * float(n_target) ** 3), "unit": "evals/s", "cores": 1, "kind": "port",
@@ -156,7 +161,7 @@ def cpu_baseline(d, n_target, fitc_n, fitc_m):
                        f"{a1 * float(n_target) ** 3 / 3600:.1f} h per evaluation at n={n_target} "
                        "(the reference as shipped is single-threaded, CMakeLists.txt:12; this scalar port runs at a few "
                        "GFLOP/s, slower than the Eigen build it stands in for)",
-           "measured_s_1_thread": {str(n): t for n, t in one.items()},
+           "measured_s_1_thread": {str(n): t for n, t in one.items()}, "fitted_exponent_1_thread": p1,
            "all_cores": {"value": 1.0 / (aN * float(n_target) ** 3), "unit": "evals/s", "cores": threads, "kind": "port",
                          "sample": "same restatement built with -fopenmp (oracle/libgporacle_omp.so), measured "
                                    + ", ".join(f"n={n}: {t:.2f} s" for n, t in allc.items())
@@ -291,6 +296,21 @@ def pmc_traffic():
     return None, None, None
 
 
+def pmc_kernel_traffic(fname, prefixes):
+    """HBM-side bytes per launch (FETCH_SIZE corrected + WRITE_SIZE) of the first kernel whose name starts with one
+    of `prefixes`, from the newest committed --pmc summary `profiles/<dir>/<fname>`; (GB, source) or (None, None)."""
+    for dname in PMC_DIRS:
+        path = os.path.join(ROOT, "profiles", dname, fname)
+        if not os.path.exists(path):
+            continue
+        d = json.load(open(path))
+        for pre in prefixes:
+            for k, v in d.items():
+                if k.startswith(pre) and "fetch_bytes_per_launch_corrected" in v and "write_bytes_per_launch" in v:
+                    return (v["fetch_bytes_per_launch_corrected"] + v["write_bytes_per_launch"]) / 1e9, f"profiles/{dname}/{fname}: {k}"
+    return None, None
+
+
 def timed(D, lib, fn, steps, warmup, prof_min_flops, pair_min_bytes=None):
     out = None
     for _ in range(warmup):
@@ -319,13 +339,17 @@ def timed(D, lib, fn, steps, warmup, prof_min_flops, pair_min_bytes=None):
     return D.max_over_ranks(dt), out, prof
 
 
-def hbm_roofline(kernel, p, note):
-    """`roofline`-shaped object of one HBM-bound kernel: algorithmic bytes / live HIP-event duration"""
+def hbm_roofline(kernel, p, note, pmc=None):
+    """`roofline`-shaped object of one HBM-bound kernel: algorithmic bytes / live HIP-event duration; `traffic` =
+    HBM-side GB per launch from the committed --pmc passes of the same workload (pmc = (file, kernel-name prefixes))"""
     if not p or p["launches"] == 0 or p["ms"] <= 0:
         return None
     gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9
+    traffic, src = pmc_kernel_traffic(*pmc) if pmc else (None, None)
     return {"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gbs / HBM_PEAK_GBS, "traffic": None, "launches_per_eval": p["launches"],
+            "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_unit": "GB per launch (FETCH_SIZE gfx950-corrected + WRITE_SIZE, separate --pmc passes)",
+            "traffic_source": src, "launches_per_eval": p["launches"],
             "kernel_ms_per_eval": p["ms"], "algorithmic_bytes_per_eval": p["bytes"], "note": note}
 
 
@@ -402,6 +426,95 @@ def run_sparse(D, lib, synth, model, n, m, d, steps, warmup, cfg_index, want_t1)
     return dt, nll, prof, hook, t1
 
 
+def run_config0(lib, with_cpu=True):
+    """BASELINE configs[0] / BASELINE.md section 2 "Config #1": the reference's own sample data (data/train_x|train_y,
+    d = 24; tests/golden/refdata_full.npz holds the data), exact GP SE-ARD as `gp num_train` runs it (mygp.cpp:9-39):
+    one NLL+gradient evaluation at the default hypers (GP.cpp:85-92), _setK, and batch_predict of the 2000 rows of
+    data/test_x, at num_train = 500 / 2000 / 8000, on the GPU beside the CPU port (oracle: 1 thread and all cores at
+    500 / 2000; 8000 extrapolated with n^3 and labelled), plus the facade's `gp 8000` MLE run (wall time, evaluations)."""
+    import re
+    import tempfile
+    g = np.load(os.path.join(ROOT, "tests", "golden", "refdata_full.npz"))
+    Xall, yall, Xs = g["X"], g["y"], g["Xs"]
+    res = {"workload": "exact GP SE-ARD on the reference's data/train_x|train_y (d=24), default hypers: NLL+grad, _setK, "
+                       "batch_predict of data/test_x (2000 rows) (BASELINE configs[0])", "sizes": {}}
+    cpu = {}
+    for n in (500, 2000, 8000):
+        X, y = Xall[:n], yall[:n]
+        hyp = g[f"ard_default_hyp_{n}"]
+        ctx = lib.Context(0)
+        ctx.set_data(X, y)
+        ctx.nll_grad(lib.MODEL_EXACT, lib.COV_SE_ARD, hyp)   # warm-up (allocations)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            nll, _g = ctx.nll_grad(lib.MODEL_EXACT, lib.COV_SE_ARD, hyp)
+            ts.append(time.perf_counter() - t0)
+        ctx.prepare(lib.MODEL_EXACT, lib.COV_SE_ARD, hyp)
+        ctx.predict(Xs[:64])
+        t0 = time.perf_counter()
+        ctx.prepare(lib.MODEL_EXACT, lib.COV_SE_ARD, hyp)
+        t_setk = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        mu, s2 = ctx.predict(Xs)
+        t_pred = time.perf_counter() - t0
+        ctx.close()
+        e = {"nll": nll, "gpu_nll_grad_ms": 1e3 * float(np.median(ts)), "gpu_setK_ms": 1e3 * t_setk,
+             "gpu_predict_2000_ms": 1e3 * t_pred, "mean_pred_std": float(np.sqrt(s2).mean())}
+        if with_cpu:
+            import oracle
+            if n <= 2000:
+                t0 = time.perf_counter()
+                nll_o, _go = oracle.exact_nll(oracle.COV_SE_ARD, X, y, hyp)
+                c1 = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                oracle.exact_nll_all_cores(oracle.COV_SE_ARD, X, y, hyp)
+                cN = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                st = oracle.ExactState(oracle.COV_SE_ARD, X, y, hyp)
+                mu_o, s2_o = st.predict(Xs)
+                cP = time.perf_counter() - t0
+                cpu[n] = (c1, cN, cP)
+                e.update({"cpu_port_nll_grad_s_1_thread": c1, "cpu_port_nll_grad_s_all_cores": cN,
+                          "cpu_port_setK_plus_predict_2000_s_1_thread": cP,
+                          "nll_rel_err_vs_cpu_port": abs(nll - nll_o) / abs(nll_o),
+                          "mu_rel_err_vs_cpu_port": float(np.max(np.abs(mu - mu_o)) / np.max(np.abs(mu_o)))})
+            else:
+                f = (n / 2000.0) ** 3
+                e.update({"cpu_port_nll_grad_s_1_thread_extrapolated": cpu[2000][0] * f,
+                          "cpu_port_nll_grad_s_all_cores_extrapolated": cpu[2000][1] * f,
+                          "extrapolation": "measured n = 2000 times x (8000/2000)^3"})
+        res["sizes"][str(n)] = e
+    if with_cpu:
+        res["cpu_port_threads_all_cores"] = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or len(os.sched_getaffinity(0))
+    # `gp 8000`: the facade's demo program (gp_amd/host/demos/demo.cpp = mygp.cpp) as a child process on the text files
+    exe = os.path.join(ROOT, "gp_amd", "host", "bin", "gp")
+    if os.path.exists(exe):
+        with tempfile.TemporaryDirectory() as td:
+            np.savetxt(os.path.join(td, "train_x"), Xall, fmt="%.17g")
+            np.savetxt(os.path.join(td, "train_y"), yall, fmt="%.17g")
+            np.savetxt(os.path.join(td, "test_x"), Xs, fmt="%.17g")
+            t0 = time.perf_counter()
+            pr = subprocess.run([exe, "8000"], cwd=td, capture_output=True, text=True, timeout=600)
+            wall = time.perf_counter() - t0
+            mle = {"command": "gp 8000 (MLE from the default hypers, maxeval 160 (GP.cpp:232), _setK, batch_predict of 2000 points, pred file)",
+                   "returncode": pr.returncode, "process_wall_s": wall}
+            for key, pat in (("training_time_s", r"Training time: ([0-9.eE+-]+)"), ("prediction_time_s", r"Prediction time: ([0-9.eE+-]+)"),
+                             ("final_nll", r"Negative log likelihood: ([0-9.eE+-]+)")):
+                mm = re.search(pat, pr.stdout)
+                if mm:
+                    mle[key] = float(mm.group(1))
+            mm = re.search(r"after (\d+) evaluations \(([^)]*)\)", pr.stdout + pr.stderr)
+            if mm:
+                mle["evaluations"], mle["optimizer"] = int(mm.group(1)), mm.group(2)
+            if os.path.exists(os.path.join(td, "pred")):
+                pred = np.loadtxt(os.path.join(td, "pred"))
+                mle["pred_rows"] = int(pred.shape[0])
+                mle["rmse_vs_data_test_y (sanity, never asserted)"] = float(np.sqrt(np.mean((pred[:, 0] - g["ys"]) ** 2)))
+            res["mle_gp_8000"] = mle
+    return res
+
+
 def main():
     args = parse_args()
     in_group = "WORLD_SIZE" in os.environ or "RANK" in os.environ
@@ -429,7 +542,8 @@ def main():
     from gp_amd import lib, synth
     lib.lib.gpx_prof_pairwise_begin.argtypes = [C.c_double, C.c_int]
     lib.lib.gpx_prof_pairwise_end.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    want = {"default": ("exact", "exact8192", "fitc"), "all": ("exact", "exact8192", "fitc", "vfe")}.get(args.workload, (args.workload,))
+    full = ("exact", "exact8192", "fitc", "vfe", "config0")   # every BASELINE config in the one line the driver records
+    want = {"default": full, "all": full}.get(args.workload, (args.workload,))
     out = {"metric": METRIC, "unit": "evals/s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
            "higher_is_better": True, "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
     if D.dist is not None:
@@ -461,9 +575,11 @@ def main():
                          "flops_in_other_gemm_launches_per_eval": prof["small_flops"]},
             "hbm_rooflines": [r for r in (
                 hbm_roofline("cov_build_kernel (K + sn2 I, lower triangle)", prof.get("cov_build"),
-                             "algorithmic bytes = 4 n^2 written; VALU-bound (exp + direct differences), DESIGN.md §3.3"),
-                hbm_roofline("pair_trace_kernel (fused gradient trace over (K+sn2 I)^-1)", prof.get("pair_trace"),
-                             "algorithmic bytes = 4 n^2 read")) if r],
+                             "algorithmic bytes = 4 n^2 written; VALU-bound (exp + direct differences), DESIGN.md §3.3",
+                             ("exact_n65536_traffic.json", ("cov_build_kernel",)) if n == 65536 else None),
+                hbm_roofline("gradient trace over (K+sn2 I)^-1 (trace_sym_mfma_kernel / pair_trace_kernel)", prof.get("pair_trace"),
+                             "algorithmic bytes = 4 n^2 read",
+                             ("exact_n65536_traffic.json", ("trace_sym_mfma_kernel", "pair_trace_kernel")) if n == 65536 else None)) if r],
         })
         if pred is not None:
             out["predict"] = pred
@@ -483,13 +599,15 @@ def main():
         if model not in want:
             continue
         n, m, d = (args.fitc_n, args.fitc_m, args.d) if model == "fitc" else (args.vfe_n, args.vfe_m, args.vfe_d)
-        dt, nll, prof, hook, t1 = run_sparse(D, lib, synth, model, n, m, d, args.sparse_steps, 1, 3 if model == "fitc" else 4,
+        default_size = (n, m, d) == ((1 << 20, 1024, 20) if model == "fitc" else (1 << 22, 2048, 50))
+        sp_steps = args.sparse_steps if model == "fitc" else args.vfe_steps
+        dt, nll, prof, hook, t1 = run_sparse(D, lib, synth, model, n, m, d, sp_steps, 1, 3 if model == "fitc" else 4,
                                              not args.no_t1)
         flops = (6.0 if model == "fitc" else 3.0) * n * m * m
-        tf = flops * args.sparse_steps / dt / 1e12
+        tf = flops * sp_steps / dt / 1e12
         gemm_tf = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] > 0 else 0.0
-        sub = {"value": args.sparse_steps / dt, "unit": "evals/s", "ms_per_step": 1e3 * dt / args.sparse_steps,
-               "scaling": "strong", "n_gpus": D.world, "steps": args.sparse_steps,
+        sub = {"value": sp_steps / dt, "unit": "evals/s", "ms_per_step": 1e3 * dt / sp_steps,
+               "scaling": "strong", "n_gpus": D.world, "steps": sp_steps,
                "config": {"workload": f"{model.upper()} SE-ARD NLL+grad, n={n} m={m} d={d}, rows sharded over "
                                       f"{D.world} GPU(s), RCCL all-reduce of m x m partials", "n": n, "m": m, "d": d},
                "nll": nll, "algorithmic_tflops_total": tf,
@@ -497,18 +615,20 @@ def main():
                "per_rank_ms": prof["per_rank_ms"],
                "gemm_ms_per_eval_rank0": prof["gemm_ms"], "gemm_tflops_rank0": gemm_tf,
                "hbm_rooflines": [r for r in (
-                   hbm_roofline("Kxu build (cov_build / cov_mfma kernel)", prof.get("cov_build"), "algorithmic bytes = 8 n m written"),
-                   hbm_roofline("fused gradient trace over W_xu (pair_trace kernel)", prof.get("pair_trace"),
-                                "algorithmic bytes = the n x m weight matrices read (2 for FITC, 1 for VFE)")) if r]}
+                   hbm_roofline("Kxu build (cov_mfma_kernel)", prof.get("cov_build"), "algorithmic bytes = 8 n m written",
+                                (f"{model}_traffic.json", ("cov_mfma_kernel", "cov_build_kernel")) if default_size else None),
+                   hbm_roofline("fused gradient trace over W_xu (trace_mfma*_kernel)", prof.get("pair_trace"),
+                                "algorithmic bytes = the n x m weight matrices read (2 for FITC, 1 for VFE)",
+                                (f"{model}_traffic.json", ("trace_mfma", "pair_trace_kernel")) if default_size else None)) if r]}
         if hook:
             sub.update(hook)
         if t1 is not None:
             sub["t1_ms_single_gpu_same_run"] = 1e3 * t1
-            sub["parallel_efficiency"] = t1 / (D.world * dt / args.sparse_steps)
+            sub["parallel_efficiency"] = t1 / (D.world * dt / sp_steps)
         out[model] = sub
         if "value" not in out:
             out.update({"value": sub["value"], "ms_per_step": sub["ms_per_step"], "scaling": "strong",
-                        "config": sub["config"], "steps": args.sparse_steps})
+                        "config": sub["config"], "steps": sp_steps})
 
     if D.rank == 0:
         best = 0.0
@@ -517,6 +637,12 @@ def main():
             lib.check(lib.lib.gpx_bench_mfma_f64_peak(C.byref(peak)), "mfma_peak")
             best = max(best, peak.value)
         out["measured_bare_mfma_f64_tflops"] = best   # register-operand MFMA loop, 16 accumulators, 2 waves/SIMD
+        if "config0" in want and D.world == 1:
+            out["config0"] = run_config0(lib, with_cpu=not args.no_cpu_baseline)
+            if "value" not in out:
+                c2k = out["config0"]["sizes"]["2000"]
+                out.update({"value": 1e3 / c2k["gpu_nll_grad_ms"], "ms_per_step": c2k["gpu_nll_grad_ms"], "scaling": "weak",
+                            "config": {"workload": out["config0"]["workload"] + " (num_train = 2000)"}})
         if not args.no_cpu_baseline and D.world == 1 and "exact" in want:
             out["cpu_baseline"] = cpu_baseline(args.d, args.n, args.fitc_n, args.fitc_m)   # ~45 s of CPU work
         sys.stdout.flush()

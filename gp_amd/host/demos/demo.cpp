@@ -47,6 +47,7 @@ int main(int argc, char** argv) {
     const double nlz = gp.train(init);
 #endif
     const auto t2 = std::chrono::high_resolution_clock::now();
+    std::cerr << "optimizer: " << gp.last_optimizer_status() << std::endl;   // not in the reference's output: stderr
     std::cout << "Training time: " << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() * 1e-3
               << " seconds" << std::endl;
     std::cout << "Negative log likelihood: " << nlz << std::endl;

@@ -208,3 +208,29 @@ def test_sparse_full_size_directional_derivative(gpx, model):
     M = gpx.MODEL_FITC if model == "fitc" else gpx.MODEL_VFE
     _directional_check(ctx, gpx, M, hyp, 1e-4, jitter=1e-8, tol=1e-5)
     ctx.close()
+
+
+def test_config0_reference_data_num_train_2000_matches_oracle(gpx):
+    """BASELINE configs[0]: `gp 2000` on the reference's own data/train_x|train_y (tests/golden/refdata_full.npz holds
+    the data; the reference holds no outputs, so the expected values come from the oracle: parity unpinned) at the
+    default hypers of GP.cpp:85-92 — NLL, gradient, _setK and the batch prediction of the first 500 rows of data/test_x."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "refdata_full.npz"))
+    n = 2000
+    X, y, Xs = g["X"][:n], g["y"][:n], g["Xs"][:500]
+    hyp = g["ard_default_hyp_2000"]
+    assert np.array_equal(hyp, oracle.default_hyps(oracle.COV_SE_ARD, X, y))
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    nll, gr = ctx.nll_grad(gpx.MODEL_EXACT, gpx.COV_SE_ARD, hyp)
+    hyp_p, _ = ctx.prepare(gpx.MODEL_EXACT, gpx.COV_SE_ARD, hyp)
+    mu, s2 = ctx.predict(Xs)
+    ctx.close()
+    nll_o, g_o = oracle.exact_nll_all_cores(oracle.COV_SE_ARD, X, y, hyp)
+    st = oracle.ExactState(oracle.COV_SE_ARD, X, y, hyp)
+    mu_o, s2_o = st.predict(Xs)
+    e = (abs(nll - nll_o) / abs(nll_o), float(np.max(np.abs(gr - g_o)) / np.max(np.abs(g_o))),
+         float(np.max(np.abs(mu - mu_o)) / np.max(np.abs(mu_o))), float(np.max(np.abs(s2 - s2_o)) / np.max(np.abs(s2_o))))
+    print(f"\n[config0 num_train=2000] rel err vs oracle: NLL {e[0]:.2e} gradient {e[1]:.2e} mean {e[2]:.2e} variance {e[3]:.2e}")
+    assert np.array_equal(hyp_p, hyp)            # no noise escalation at the default hypers
+    assert e[0] <= 1e-9 and e[1] <= 1e-7 and e[2] <= 1e-9 and e[3] <= 1e-9

@@ -61,5 +61,22 @@ def main(data_dir):
     print("sanity RMSE of exact-GP mean vs data/test_y (never asserted):", rmse, "std(ys)", ys.std())
 
 
+def full(data_dir):
+    """tests/golden/refdata_full.npz: the reference's whole sample data set (BASELINE configs[0]: `gp num_train` on
+    data/train_x|train_y, 8000 x 24, predictions on the 2000 rows of data/test_x) as DATA, plus the default hypers of
+    GP.cpp:85-92 at the three sizes BASELINE.md section 2 names (from the oracle; the reference holds no outputs)."""
+    X = np.loadtxt(os.path.join(data_dir, "train_x"))
+    y = np.loadtxt(os.path.join(data_dir, "train_y"))
+    Xs = np.loadtxt(os.path.join(data_dir, "test_x"))
+    ys = np.loadtxt(os.path.join(data_dir, "test_y"))
+    out = dict(X=X, y=y, Xs=Xs, ys=ys)
+    for n in (500, 2000, 8000):
+        out[f"ard_default_hyp_{n}"] = oracle.default_hyps(oracle.COV_SE_ARD, X[:n], y[:n])
+    path = os.path.join(ROOT, "tests", "golden", "refdata_full.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes", X.shape, Xs.shape)
+
+
 if __name__ == "__main__":
     main(sys.argv[1] if len(sys.argv) > 1 else "/root/reference/data")
+    full(sys.argv[1] if len(sys.argv) > 1 else "/root/reference/data")
