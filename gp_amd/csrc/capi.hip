@@ -6,6 +6,20 @@
 
 extern "C" {
 
+// restores the caller's current device on every exit path of an entry point that has to switch it
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (dev >= 0 && dev != prev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
 int gpx_ctx_create(int device, gpx_ctx** out) {
     if (!out) return GPX_ERR_ARG;
     *out = nullptr;
@@ -22,28 +36,36 @@ int gpx_ctx_create(int device, gpx_ctx** out) {
         e = getenv("GPX_FITC_NO_WHITEN");
         c->fitc_whiten = !(e && e[0] == '1');
     }
-    // non-blocking: no implicit ordering against the caller's NULL-stream work (e.g. a collective a
-    // framework issues from the all-reduce hook); every entry point drains its own streams
-    HIP_TRY(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
-    // the side stream carries short dependent chains that run beside a chip-filling GEMM: highest
-    // priority, so that their workgroups take the next CU slot that frees up
-    int prio_lo = 0, prio_hi = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    HIP_TRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, prio_hi));
-    for (auto& e : c->ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->info), 64));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->host_scal), 1024 * sizeof(double)));
-    int rc = c->scal.ensure(1024);
-    if (!rc) rc = c->trace_ws.ensure(GPX_TRACE_WS);
-    if (rc) return rc;
+    // every failing step releases what the steps before it created (gpx_ctx_destroy copes with a half-built context)
+    auto build = [&]() -> int {
+        // non-blocking: no implicit ordering against the caller's NULL-stream work (e.g. a collective a
+        // framework issues from the all-reduce hook); every entry point drains its own streams
+        HIP_TRY(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+        // the side stream carries short dependent chains that run beside a chip-filling GEMM: highest
+        // priority, so that their workgroups take the next CU slot that frees up
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIP_TRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, prio_hi));
+        for (auto& e : c->ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->info), 64));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->host_scal), 1024 * sizeof(double)));
+        int rc = c->scal.ensure(1024);
+        if (!rc) rc = c->trace_ws.ensure(GPX_TRACE_WS);
+        return rc;
+    };
+    const int rc = build();
+    if (rc) {
+        gpx_ctx_destroy(c);
+        return rc;
+    }
     *out = c;
     return GPX_OK;
 }
 
 int gpx_ctx_destroy(gpx_ctx* c) {
     if (!c) return GPX_OK;
-    (void)hipSetDevice(c->dev);
-    (void)hipStreamSynchronize(c->st);
+    DeviceGuard dg(c->dev);
+    if (c->st) (void)hipStreamSynchronize(c->st);
     if (c->st2) (void)hipStreamSynchronize(c->st2);
     DevBuf* bufs[] = {&c->X, &c->y, &c->U, &c->Xt, &c->Ut, &c->A, &c->W, &c->T, &c->Wd, &c->r, &c->alpha,
                       &c->nalpha, &c->scal, &c->trace_ws, &c->Kxu, &c->V, &c->Bm, &c->Cm, &c->Kuu, &c->Lu,
@@ -56,7 +78,7 @@ int gpx_ctx_destroy(gpx_ctx* c) {
     for (auto& b : c->vm) b.release();
     if (c->info) (void)hipFree(c->info);
     if (c->host_scal) (void)hipHostFree(c->host_scal);
-    (void)hipStreamDestroy(c->st);
+    if (c->st) (void)hipStreamDestroy(c->st);
     if (c->st2) (void)hipStreamDestroy(c->st2);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -179,73 +201,35 @@ int gpx_cov_k(int cov, int64_t d, const double* hyp, const double* x1, int64_t p
     return rc;
 }
 
-int gpx_chol_solve(int64_t n, const double* A, int* spd, double* logdet, double* B, int64_t nrhs, double* Inv) {
-    if (!A || !spd || n <= 0 || nrhs < 0 || (nrhs > 0 && !B)) return GPX_ERR_ARG;
-    const long ld = gpx_ld(n);
-    DevBuf L, Wd, W, T, Bd, sc;
-    int* info = nullptr;
-    int rc = L.ensure(ld * n);
-    if (!rc) rc = Wd.ensure(64L * ((n + 63) / 64 * 64));
-    if (!rc) rc = sc.ensure(8);
-    if (!rc && hipMalloc(reinterpret_cast<void**>(&info), 64) != hipSuccess) rc = GPX_ERR_HIP;
-    auto done = [&](int r) {
-        L.release(); Wd.release(); W.release(); T.release(); Bd.release(); sc.release();
-        if (info) (void)hipFree(info);
-        return r;
-    };
-    if (rc) return done(rc);
-    if (hipMemcpy2D(L.p, ld * 8, A, n * 8, n * 8, n, hipMemcpyHostToDevice) != hipSuccess) return done(GPX_ERR_HIP);
-    if (hipMemset(info, 0, 4) != hipSuccess) return done(GPX_ERR_HIP);
-    if ((rc = gpx_potrf(0, n, L.p, ld, Wd.p, info))) return done(rc);
-    int hinfo = 0;
-    if (hipMemcpy(&hinfo, info, 4, hipMemcpyDeviceToHost) != hipSuccess) return done(GPX_ERR_HIP);
-    *spd = hinfo == 0;
-    if (!*spd) return done(GPX_OK);
-    if (logdet) {
-        if ((rc = gpx_logdiag_sum(0, n, L.p, ld, sc.p))) return done(rc);
-        double s;
-        if (hipMemcpy(&s, sc.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return done(GPX_ERR_HIP);
-        *logdet = 2 * s;
-    }
-    if (nrhs > 0) {
-        if ((rc = Bd.ensure(ld * nrhs))) return done(rc);
-        if (hipMemcpy2D(Bd.p, ld * 8, B, n * 8, n * 8, nrhs, hipMemcpyHostToDevice) != hipSuccess) return done(GPX_ERR_HIP);
-        if ((rc = gpx_trsm_left(0, n, nrhs, L.p, ld, Wd.p, Bd.p, ld, 0))) return done(rc);
-        if ((rc = gpx_trsm_left(0, n, nrhs, L.p, ld, Wd.p, Bd.p, ld, 1))) return done(rc);
-        if (hipMemcpy2D(B, n * 8, Bd.p, ld * 8, n * 8, nrhs, hipMemcpyDeviceToHost) != hipSuccess) return done(GPX_ERR_HIP);
-    }
-    if (Inv) {
-        if ((rc = W.ensure(ld * n)) || (rc = T.ensure(gpx_trtri_scratch(n)))) return done(rc);
-        if (hipMemset(W.p, 0, (size_t)ld * n * 8) != hipSuccess) return done(GPX_ERR_HIP);
-        if ((rc = gpx_trtri(0, n, L.p, ld, Wd.p, W.p, ld, T.p))) return done(rc);
-        if ((rc = gpx_lauum(0, n, W.p, ld, L.p, ld))) return done(rc);
-        if (hipMemcpy2D(Inv, n * 8, L.p, ld * 8, n * 8, n, hipMemcpyDeviceToHost) != hipSuccess) return done(GPX_ERR_HIP);
-        // mirror the lower triangle (the device keeps only the lower tiles)
-        for (int64_t j = 0; j < n; ++j)
-            for (int64_t i = j + 1; i < n; ++i) Inv[j + i * n] = Inv[i + j * n];
-    }
-    return done(GPX_OK);
-}
-
 // ---- MatrixSolverLLT with the factor kept on the device between decomp() and solve() / inverse() ----
+// The handle belongs to ONE device (the `device` argument of gpx_chol_factor; -1 = the caller's current one); every
+// entry point switches to it and restores the caller's current device on every exit path.  The solve / inverse
+// staging buffers live in the handle: no hipMalloc / hipFree per solve() once they have grown to size.
 struct gpx_chol {
     int dev = 0;
     long n = 0, ld = 0;
     DevBuf L, Wd;
+    mutable DevBuf Bd, W, T, O;
+    hipStream_t st = nullptr;
     bool spd = false;
 };
 
-int gpx_chol_factor(int64_t n, const double* A, gpx_chol** out, int* spd, double* logdet) {
+static void chol_release(gpx_chol* f) {
+    f->L.release(); f->Wd.release(); f->Bd.release(); f->W.release(); f->T.release(); f->O.release();
+    if (f->st) (void)hipStreamDestroy(f->st);
+    delete f;
+}
+
+int gpx_chol_factor(int device, int64_t n, const double* A, gpx_chol** out, int* spd, double* logdet) {
     if (!A || !out || !spd || n <= 0) return GPX_ERR_ARG;
     *out = nullptr;
+    DeviceGuard dg(device);
+    if (!dg.ok) return GPX_ERR_ARG;
     gpx_chol* f = new (std::nothrow) gpx_chol();
     if (!f) return GPX_ERR_HIP;
-    auto fail = [&](int r) {
-        f->L.release(); f->Wd.release();
-        delete f;
-        return r;
-    };
+    auto fail = [&](int r) { chol_release(f); return r; };
     if (hipGetDevice(&f->dev) != hipSuccess) return fail(GPX_ERR_HIP);
+    if (hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking) != hipSuccess) return fail(GPX_ERR_HIP);
     f->n = n;
     f->ld = gpx_ld(n);
     int rc = f->L.ensure(f->ld * n);
@@ -253,17 +237,19 @@ int gpx_chol_factor(int64_t n, const double* A, gpx_chol** out, int* spd, double
     if (rc) return fail(rc);
     int* info = reinterpret_cast<int*>(f->Wd.p + 64L * ((n + 63) / 64 * 64));  // device flag + log-det slot behind Wd
     double* sc = f->Wd.p + 64L * ((n + 63) / 64 * 64) + 8;
-    if (hipMemcpy2D(f->L.p, f->ld * 8, A, n * 8, n * 8, n, hipMemcpyHostToDevice) != hipSuccess) return fail(GPX_ERR_HIP);
-    if (hipMemset(info, 0, 8) != hipSuccess) return fail(GPX_ERR_HIP);
-    if ((rc = gpx_potrf(0, n, f->L.p, f->ld, f->Wd.p, info))) return fail(rc);
+    if (hipMemcpy2DAsync(f->L.p, f->ld * 8, A, n * 8, n * 8, n, hipMemcpyHostToDevice, f->st) != hipSuccess) return fail(GPX_ERR_HIP);
+    if (hipMemsetAsync(info, 0, 8, f->st) != hipSuccess) return fail(GPX_ERR_HIP);
+    if ((rc = gpx_potrf(f->st, n, f->L.p, f->ld, f->Wd.p, info))) return fail(rc);
     int hinfo = 0;
-    if (hipMemcpy(&hinfo, info, 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(GPX_ERR_HIP);
+    if (hipMemcpyAsync(&hinfo, info, 4, hipMemcpyDeviceToHost, f->st) != hipSuccess) return fail(GPX_ERR_HIP);
+    if (hipStreamSynchronize(f->st) != hipSuccess) return fail(GPX_ERR_HIP);
     f->spd = hinfo == 0;
     *spd = f->spd ? 1 : 0;
     if (f->spd && logdet) {
-        if ((rc = gpx_logdiag_sum(0, n, f->L.p, f->ld, sc))) return fail(rc);
+        if ((rc = gpx_logdiag_sum(f->st, n, f->L.p, f->ld, sc))) return fail(rc);
         double v;
-        if (hipMemcpy(&v, sc, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(GPX_ERR_HIP);
+        if (hipMemcpyAsync(&v, sc, 8, hipMemcpyDeviceToHost, f->st) != hipSuccess) return fail(GPX_ERR_HIP);
+        if (hipStreamSynchronize(f->st) != hipSuccess) return fail(GPX_ERR_HIP);
         *logdet = 2 * v;
     }
     *out = f;
@@ -273,46 +259,55 @@ int gpx_chol_factor(int64_t n, const double* A, gpx_chol** out, int* spd, double
 int gpx_chol_solve_factored(const gpx_chol* f, double* B, int64_t nrhs) {
     if (!f || !B || nrhs <= 0) return GPX_ERR_ARG;
     if (!f->spd) return GPX_ERR_STATE;
-    HIP_TRY(hipSetDevice(f->dev));
+    DeviceGuard dg(f->dev);
+    if (!dg.ok) return GPX_ERR_HIP;
     const long n = f->n, ld = f->ld;
-    DevBuf Bd;
-    int rc = Bd.ensure(ld * nrhs);
+    int rc = f->Bd.ensure(ld * nrhs);
     if (rc) return rc;
-    auto done = [&](int r) { Bd.release(); return r; };
-    if (hipMemcpy2D(Bd.p, ld * 8, B, n * 8, n * 8, nrhs, hipMemcpyHostToDevice) != hipSuccess) return done(GPX_ERR_HIP);
-    if ((rc = gpx_trsm_left(0, n, nrhs, f->L.p, ld, f->Wd.p, Bd.p, ld, 0))) return done(rc);
-    if ((rc = gpx_trsm_left(0, n, nrhs, f->L.p, ld, f->Wd.p, Bd.p, ld, 1))) return done(rc);
-    if (hipMemcpy2D(B, n * 8, Bd.p, ld * 8, n * 8, nrhs, hipMemcpyDeviceToHost) != hipSuccess) return done(GPX_ERR_HIP);
-    return done(GPX_OK);
+    HIP_TRY(hipMemcpy2DAsync(f->Bd.p, ld * 8, B, n * 8, n * 8, nrhs, hipMemcpyHostToDevice, f->st));
+    if ((rc = gpx_trsm_left(f->st, n, nrhs, f->L.p, ld, f->Wd.p, f->Bd.p, ld, 0))) return rc;
+    if ((rc = gpx_trsm_left(f->st, n, nrhs, f->L.p, ld, f->Wd.p, f->Bd.p, ld, 1))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(B, n * 8, f->Bd.p, ld * 8, n * 8, nrhs, hipMemcpyDeviceToHost, f->st));
+    HIP_TRY(hipStreamSynchronize(f->st));
+    return GPX_OK;
 }
 
 int gpx_chol_inverse_factored(const gpx_chol* f, double* Inv) {
     if (!f || !Inv) return GPX_ERR_ARG;
     if (!f->spd) return GPX_ERR_STATE;
-    HIP_TRY(hipSetDevice(f->dev));
+    DeviceGuard dg(f->dev);
+    if (!dg.ok) return GPX_ERR_HIP;
     const long n = f->n, ld = f->ld;
-    DevBuf W, T, O;
-    int rc = W.ensure(ld * n);
-    if (!rc) rc = T.ensure(gpx_trtri_scratch(n));
-    if (!rc) rc = O.ensure(ld * n);
-    auto done = [&](int r) { W.release(); T.release(); O.release(); return r; };
-    if (rc) return done(rc);
-    if (hipMemset(W.p, 0, (size_t)ld * n * 8) != hipSuccess) return done(GPX_ERR_HIP);
-    if ((rc = gpx_trtri(0, n, f->L.p, ld, f->Wd.p, W.p, ld, T.p))) return done(rc);
-    if ((rc = gpx_lauum(0, n, W.p, ld, O.p, ld))) return done(rc);
-    if (hipMemcpy2D(Inv, n * 8, O.p, ld * 8, n * 8, n, hipMemcpyDeviceToHost) != hipSuccess) return done(GPX_ERR_HIP);
-    for (int64_t j = 0; j < n; ++j)   // the device keeps only the lower tiles
-        for (int64_t i = j + 1; i < n; ++i) Inv[j + i * n] = Inv[i + j * n];
-    return done(GPX_OK);
+    int rc = f->W.ensure(ld * n);
+    if (!rc) rc = f->T.ensure(gpx_trtri_scratch(n));
+    if (!rc) rc = f->O.ensure(ld * n);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(f->W.p, 0, (size_t)ld * n * 8, f->st));
+    if ((rc = gpx_trtri(f->st, n, f->L.p, ld, f->Wd.p, f->W.p, ld, f->T.p))) return rc;
+    if ((rc = gpx_lauum(f->st, n, f->W.p, ld, f->O.p, ld))) return rc;
+    if ((rc = gpx_symmetrize_lower(f->st, n, f->O.p, ld))) return rc;   // the device keeps only the lower tiles
+    HIP_TRY(hipMemcpy2DAsync(Inv, n * 8, f->O.p, ld * 8, n * 8, n, hipMemcpyDeviceToHost, f->st));
+    HIP_TRY(hipStreamSynchronize(f->st));
+    return GPX_OK;
 }
 
 int gpx_chol_free(gpx_chol* f) {
     if (!f) return GPX_OK;
-    (void)hipSetDevice(f->dev);
-    f->L.release();
-    f->Wd.release();
-    delete f;
+    DeviceGuard dg(f->dev);
+    chol_release(f);
     return GPX_OK;
+}
+
+// one-shot flavour: decomp + solve + inverse + free on the caller's current device
+int gpx_chol_solve(int64_t n, const double* A, int* spd, double* logdet, double* B, int64_t nrhs, double* Inv) {
+    if (!A || !spd || n <= 0 || nrhs < 0 || (nrhs > 0 && !B)) return GPX_ERR_ARG;
+    gpx_chol* f = nullptr;
+    int rc = gpx_chol_factor(-1, n, A, &f, spd, logdet);
+    if (rc) return rc;
+    if (*spd && nrhs > 0) rc = gpx_chol_solve_factored(f, B, nrhs);
+    if (!rc && *spd && Inv) rc = gpx_chol_inverse_factored(f, Inv);
+    gpx_chol_free(f);
+    return rc;
 }
 
 }  // extern "C"

@@ -99,6 +99,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
                         double* nll, double* grad);
 int gpx_sparse_prepare(gpx_ctx* c, int model, int cov, const double* hyp, double* jitter);
 int gpx_sparse_predict(gpx_ctx* c, const double* Xs, long t, double* mu, double* s2, double* gmu, double* gs2);
+int gpx_symmetrize_lower(hipStream_t st, long n, double* A, long lda);   // mirrors the lower triangle into the upper one
 // small shared kernels (exact.hip)
 int gpx_vec_shift(hipStream_t st, long n, const double* y, double shift, double scale, double* out);
 int gpx_reduce3(hipStream_t st, long n, const double* a, const double* b, double* out3);

@@ -20,6 +20,7 @@
 // direction for large outputs, LOWER products as a strictly-lower launch + a diagonal band launch.
 #include <array>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include "gpx_internal.h"
@@ -758,7 +759,8 @@ int half_skip_kind(int flags) {
 // ---- optional per-launch HIP-event timing of the large GEMMs (bench.py's roofline leg) -------
 struct GemmProf {
     std::mutex mu;  // contexts on different host threads launch GEMMs concurrently
-    bool on = false;
+    std::atomic<bool> on{false};   // read outside the lock by every launch
+    int dev = -1;   // the device that was current at gpx_gemm_prof_begin: only its launches are timed (the events live there)
     bool only128 = false;  // time the 128x128-tile launches only (the kernel the roofline object names)
     double min_flops = 0;
     std::vector<hipEvent_t> ev;  // pairs
@@ -829,9 +831,11 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     const double fl = useful_flops(M, N, K, flags);
     bool timed = false;
     size_t slot = 0;
-    if (g_prof.on) {
+    if (g_prof.on.load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lk(g_prof.mu);
-        if (g_prof.on && fl >= g_prof.min_flops && (!g_prof.only128 || bt == 128) && g_prof.used + 2 <= g_prof.ev.size()) {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (g_prof.on && cur == g_prof.dev && fl >= g_prof.min_flops && (!g_prof.only128 || bt == 128) && g_prof.used + 2 <= g_prof.ev.size()) {
             timed = true;
             slot = g_prof.used;
             g_prof.used += 2;
@@ -898,6 +902,7 @@ __global__ __launch_bounds__(256, 2) void mfma_peak_kernel(double* out, int iter
 
 int gpx_gemm_prof_begin(double min_flops, int max_launches) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
+    HIP_TRY(hipGetDevice(&g_prof.dev));
     g_prof.only128 = min_flops < 0;  // negative threshold: "every 128x128-tile launch, nothing else"
     if (min_flops < 0) min_flops = 0;
     if (g_prof.ev.size() < (size_t)max_launches * 2) {

@@ -14,6 +14,7 @@
 // first index so every global access is a contiguous 512-B row per wave.
 #include "gpx_internal.h"
 #include "kernels.h"
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 
@@ -22,7 +23,8 @@ namespace {
 // ---- optional HIP-event timing of the large pairwise launches (bench.py's HBM roofline objects) ----
 struct PairProf {
     std::mutex mu;
-    bool on = false;
+    std::atomic<bool> on{false};   // read outside the lock by every launch
+    int dev = -1;                  // only launches of the device current at gpx_pair_prof_begin are timed
     double min_bytes = 0;
     std::vector<hipEvent_t> ev;  // pairs
     std::vector<double> bytes;
@@ -31,9 +33,11 @@ struct PairProf {
 } p_prof;
 
 long pp_open(hipStream_t st, int cls, double bytes) {
-    if (!p_prof.on) return -1;
+    if (!p_prof.on.load(std::memory_order_acquire)) return -1;
     std::lock_guard<std::mutex> lk(p_prof.mu);
-    if (!p_prof.on || bytes < p_prof.min_bytes || p_prof.used + 2 > p_prof.ev.size()) return -1;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (!p_prof.on || cur != p_prof.dev || bytes < p_prof.min_bytes || p_prof.used + 2 > p_prof.ev.size()) return -1;
     const long slot = (long)p_prof.used;
     p_prof.used += 2;
     p_prof.bytes.push_back(bytes);
@@ -421,6 +425,7 @@ void gpx_pair_prof_close(hipStream_t st, long slot) { pp_close(st, slot); }
 
 int gpx_pair_prof_begin(double min_bytes, int max_launches) {
     std::lock_guard<std::mutex> lk(p_prof.mu);
+    HIP_TRY(hipGetDevice(&p_prof.dev));
     if (p_prof.ev.size() < (size_t)max_launches * 2) {
         const size_t old = p_prof.ev.size();
         p_prof.ev.resize((size_t)max_launches * 2);

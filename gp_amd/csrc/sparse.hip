@@ -354,6 +354,12 @@ enum { S_LDU = 0, S_LDA = 1, S_FA = 2, S_TRKS = 3, S_TRAS = 4, S_P0 = 8 /* 8 par
 
 }  // namespace
 
+int gpx_symmetrize_lower(hipStream_t st, long n, double* A, long lda) {
+    if (n <= 0) return GPX_OK;
+    hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(n * n)), dim3(256), 0, st, n, A, lda);
+    return GPX_OK;
+}
+
 int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int calc_grad, double jitter,
                         double* nll, double* grad) {
     if (c->n <= 0 || c->m <= 0) return GPX_ERR_STATE;

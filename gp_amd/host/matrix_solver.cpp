@@ -19,7 +19,7 @@ void MatrixSolverLLT::decomp(const MatrixXd& x) {
     _n = x.rows();
     int spd = 0;
     _logdet = std::numeric_limits<double>::quiet_NaN();
-    must(gpx_chol_factor((int64_t)_n, x.data(), &_f, &spd, &_logdet), "chol_factor");
+    must(gpx_chol_factor(_device, (int64_t)_n, x.data(), &_f, &spd, &_logdet), "chol_factor");
     _spd = spd != 0;
 }
 MatrixXd MatrixSolverLLT::solve(const MatrixXd& ys) const {

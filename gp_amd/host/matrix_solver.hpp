@@ -28,9 +28,11 @@ class MatrixSolverLLT : public MatrixSolver {
     std::size_t _n = 0;
     bool _spd = false;
     double _logdet = 0;
+    int _device = -1;         // -1: the caller's current device at decomp()
 
 public:
     MatrixSolverLLT() {}
+    explicit MatrixSolverLLT(int device) : _device(device) {}   // GP::device() of the object that owns the solver
     ~MatrixSolverLLT() override;
     MatrixSolverLLT(const MatrixSolverLLT&) = delete;
     MatrixSolverLLT& operator=(const MatrixSolverLLT&) = delete;

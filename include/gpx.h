@@ -60,13 +60,16 @@ int gpx_dgemm_rowdot(int64_t M, int64_t N, int64_t K, double alpha, const double
  * runs on, held until the process ends.  Calls hipMalloc / hipFree never; the first call on a device looks
  * the array's address up once (hipGetSymbolAddress).  Limit: M*N <= GPX_NOALLOC_MAX_MN output elements
  * (e.g. the m = 1024 Gram product), larger sizes return 1 (GPX_ERR_ARG) with a message on stderr.  All
- * calls on one GPU share the array: calls that overlap in time on one GPU race.  Runs on the NULL stream
- * like gpx_dgemm_splitk and gives bit-identical results to it for a workspace of the same capacity. */
+ * calls on one GPU share the array: calls that overlap in time on one GPU race.  The kernels are launched on
+ * hip_stream (a hipStream_t; NULL = the legacy stream like gpx_dgemm_splitk, which a graph capture cannot record:
+ * callers under capture pass their capturing stream, and must have made one un-captured call on that device
+ * before, so that the address look-up is not part of the capture).  Bit-identical to gpx_dgemm_splitk for a
+ * workspace of the same capacity. */
 #define GPX_NOALLOC_WORK_DOUBLES (8L * 1024 * 1024)
 #define GPX_NOALLOC_MAX_MN (1024L * 1024)
 int gpx_dgemm_splitk_noalloc(int a_kc, int b_kc, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
                              int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
-                             int flags);
+                             int flags, void* hip_stream);
 
 /* ---- measurement hooks (no reference counterpart) ------------------------------------------ */
 /* HIP-event timing of every GEMM launch with >= min_flops useful flops, on the launch stream; a
@@ -149,9 +152,10 @@ int gpx_chol_solve(int64_t n, const double* A, int* spd, double* logdet, double*
 
 /* The same with the factor kept ON THE DEVICE between MatrixSolver::decomp (MatrixSolver.cpp:9-12) and
  * ::solve / ::inverse (MatrixSolver.cpp:13-16, 25-28): one O(n^3) factorisation per decomp(), not one per
- * solve.  The handle belongs to the device that is current in gpx_chol_factor. */
+ * solve.  The handle belongs to `device` (-1: the caller's current device); every call switches to it and restores
+ * the caller's current device before it returns; solve / inverse staging buffers are kept in the handle. */
 typedef struct gpx_chol gpx_chol;
-int gpx_chol_factor(int64_t n, const double* A, gpx_chol** out, int* spd, double* logdet);
+int gpx_chol_factor(int device, int64_t n, const double* A, gpx_chol** out, int* spd, double* logdet);
 int gpx_chol_solve_factored(const gpx_chol* f, double* B, int64_t nrhs);
 int gpx_chol_inverse_factored(const gpx_chol* f, double* Inv);
 int gpx_chol_free(gpx_chol* f);

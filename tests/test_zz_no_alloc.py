@@ -16,7 +16,7 @@ MAX_MN = 1024 * 1024                # GPX_NOALLOC_MAX_MN
 @pytest.fixture(scope="module")
 def gpx():
     from gp_amd import lib
-    lib.lib.gpx_dgemm_splitk_noalloc.argtypes = lib.lib.gpx_dgemm.argtypes
+    lib.lib.gpx_dgemm_splitk_noalloc.argtypes = lib.lib.gpx_dgemm.argtypes + [C.c_void_p]
     return lib
 
 
@@ -28,7 +28,7 @@ def _gram(gpx, n, m, flags, noalloc, seed, beta=0.0):
     dA = gpx.DeviceBuffer.from_numpy(Kxu)
     dC = gpx.DeviceBuffer.from_numpy(gpx.colmajor(C0))
     if noalloc:
-        gpx.check(gpx.lib.gpx_dgemm_splitk_noalloc(1, 1, m, m, n, 1.0, dA.ptr, n, dA.ptr, n, beta, dC.ptr, m, flags), "noalloc")
+        gpx.check(gpx.lib.gpx_dgemm_splitk_noalloc(1, 1, m, m, n, 1.0, dA.ptr, n, dA.ptr, n, beta, dC.ptr, m, flags, None), "noalloc")
     else:
         w = gpx.DeviceBuffer(WORK_DOUBLES)
         w_fill = np.full(1 << 16, np.nan)               # a caller's workspace holds garbage too
@@ -61,6 +61,8 @@ def test_noalloc_rejects_sizes_beyond_the_static_workspace(gpx):
     assert m * m > MAX_MN
     d = gpx.DeviceBuffer(m * 64)
     c = gpx.DeviceBuffer(m * m)
-    assert gpx.lib.gpx_dgemm_splitk_noalloc(1, 1, m, m, 64, 1.0, d.ptr, 64, d.ptr, 64, 0.0, c.ptr, m, 0) == 1
+    assert gpx.lib.gpx_dgemm_splitk_noalloc(1, 1, m, m, 64, 1.0, d.ptr, 64, d.ptr, 64, 0.0, c.ptr, m, 0, None) == 1
+    # sizes whose product overflows int64 are refused by the same test, the product is never formed
+    assert gpx.lib.gpx_dgemm_splitk_noalloc(1, 1, 1 << 40, 1 << 40, 64, 1.0, d.ptr, 64, d.ptr, 64, 0.0, c.ptr, 1 << 40, 0, None) == 1
     d.free()
     c.free()
