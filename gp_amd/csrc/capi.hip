@@ -12,7 +12,10 @@ struct DeviceGuard {
     bool ok = true;
     explicit DeviceGuard(int dev) {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (dev >= 0 && dev != prev) ok = hipSetDevice(dev) == hipSuccess;
+        if (dev >= 0 && dev != prev) {
+            ok = hipSetDevice(dev) == hipSuccess;
+            if (!ok) (void)hipGetLastError();   // the refusal must not surface later as another call's "last error"
+        }
     }
     ~DeviceGuard() {
         int cur = -1;
@@ -82,6 +85,7 @@ int gpx_ctx_destroy(gpx_ctx* c) {
     if (c->st2) (void)hipStreamDestroy(c->st2);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    gpx_rccl_release(c);
     delete c;
     return GPX_OK;
 }
@@ -120,6 +124,7 @@ int gpx_set_allreduce(gpx_ctx* c, gpx_allreduce_fn fn, void* user) {
     if (!c) return GPX_ERR_ARG;
     c->allreduce = fn;
     c->allreduce_stream = nullptr;
+    c->rccl_comm = nullptr;
     c->allreduce_user = user;
     return GPX_OK;
 }
@@ -128,6 +133,7 @@ int gpx_set_allreduce_stream(gpx_ctx* c, gpx_allreduce_stream_fn fn, void* user)
     if (!c) return GPX_ERR_ARG;
     c->allreduce_stream = fn;
     c->allreduce = nullptr;
+    c->rccl_comm = nullptr;
     c->allreduce_user = user;
     return GPX_OK;
 }
@@ -220,6 +226,12 @@ static void chol_release(gpx_chol* f) {
     delete f;
 }
 
+static bool hip_bad(hipError_t e, int line) {
+    if (e == hipSuccess) return false;
+    fprintf(stderr, "gpx: HIP error %s at capi.hip:%d\n", hipGetErrorName(e), line);
+    return true;
+}
+
 int gpx_chol_factor(int device, int64_t n, const double* A, gpx_chol** out, int* spd, double* logdet) {
     if (!A || !out || !spd || n <= 0) return GPX_ERR_ARG;
     *out = nullptr;
@@ -228,8 +240,8 @@ int gpx_chol_factor(int device, int64_t n, const double* A, gpx_chol** out, int*
     gpx_chol* f = new (std::nothrow) gpx_chol();
     if (!f) return GPX_ERR_HIP;
     auto fail = [&](int r) { chol_release(f); return r; };
-    if (hipGetDevice(&f->dev) != hipSuccess) return fail(GPX_ERR_HIP);
-    if (hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking) != hipSuccess) return fail(GPX_ERR_HIP);
+    if (hip_bad(hipGetDevice(&f->dev), __LINE__)) return fail(GPX_ERR_HIP);
+    if (hip_bad(hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking), __LINE__)) return fail(GPX_ERR_HIP);
     f->n = n;
     f->ld = gpx_ld(n);
     int rc = f->L.ensure(f->ld * n);
@@ -237,19 +249,19 @@ int gpx_chol_factor(int device, int64_t n, const double* A, gpx_chol** out, int*
     if (rc) return fail(rc);
     int* info = reinterpret_cast<int*>(f->Wd.p + 64L * ((n + 63) / 64 * 64));  // device flag + log-det slot behind Wd
     double* sc = f->Wd.p + 64L * ((n + 63) / 64 * 64) + 8;
-    if (hipMemcpy2DAsync(f->L.p, f->ld * 8, A, n * 8, n * 8, n, hipMemcpyHostToDevice, f->st) != hipSuccess) return fail(GPX_ERR_HIP);
-    if (hipMemsetAsync(info, 0, 8, f->st) != hipSuccess) return fail(GPX_ERR_HIP);
+    if (hip_bad(hipMemcpy2DAsync(f->L.p, f->ld * 8, A, n * 8, n * 8, n, hipMemcpyHostToDevice, f->st), __LINE__)) return fail(GPX_ERR_HIP);
+    if (hip_bad(hipMemsetAsync(info, 0, 8, f->st), __LINE__)) return fail(GPX_ERR_HIP);
     if ((rc = gpx_potrf(f->st, n, f->L.p, f->ld, f->Wd.p, info))) return fail(rc);
     int hinfo = 0;
-    if (hipMemcpyAsync(&hinfo, info, 4, hipMemcpyDeviceToHost, f->st) != hipSuccess) return fail(GPX_ERR_HIP);
-    if (hipStreamSynchronize(f->st) != hipSuccess) return fail(GPX_ERR_HIP);
+    if (hip_bad(hipMemcpyAsync(&hinfo, info, 4, hipMemcpyDeviceToHost, f->st), __LINE__)) return fail(GPX_ERR_HIP);
+    if (hip_bad(hipStreamSynchronize(f->st), __LINE__)) return fail(GPX_ERR_HIP);
     f->spd = hinfo == 0;
     *spd = f->spd ? 1 : 0;
     if (f->spd && logdet) {
         if ((rc = gpx_logdiag_sum(f->st, n, f->L.p, f->ld, sc))) return fail(rc);
         double v;
-        if (hipMemcpyAsync(&v, sc, 8, hipMemcpyDeviceToHost, f->st) != hipSuccess) return fail(GPX_ERR_HIP);
-        if (hipStreamSynchronize(f->st) != hipSuccess) return fail(GPX_ERR_HIP);
+        if (hip_bad(hipMemcpyAsync(&v, sc, 8, hipMemcpyDeviceToHost, f->st), __LINE__)) return fail(GPX_ERR_HIP);
+        if (hip_bad(hipStreamSynchronize(f->st), __LINE__)) return fail(GPX_ERR_HIP);
         *logdet = 2 * v;
     }
     *out = f;

@@ -60,6 +60,12 @@ struct gpx_ctx {
     gpx_allreduce_fn allreduce = nullptr;                 // host-synchronous flavour
     gpx_allreduce_stream_fn allreduce_stream = nullptr;   // stream-ordered flavour (preferred)
     void* allreduce_user = nullptr;
+    // native RCCL flavour (gpx_set_allreduce_rccl): ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, stream)
+    // issued by the library itself on its own stream; optional device timing of every collective
+    void* rccl_comm = nullptr;
+    bool rccl_timing = false;
+    std::vector<hipEvent_t> rccl_ev;   // pairs
+    size_t rccl_used = 0;
     // state left by gpx_prepare for gpx_predict
     int prepared_model = -1, prepared_cov = 0;
     std::vector<double> prepared_hyp;
@@ -90,6 +96,9 @@ inline int parse_hyp(int cov, int d, const double* hyp, HypView& h) {
     return GPX_OK;
 }
 
+// rccl.hip: enqueue the in-place fp64 sum all-reduce on st through the communicator registered on c
+int gpx_rccl_allreduce(gpx_ctx* c, double* buf, long count, hipStream_t st);
+void gpx_rccl_release(gpx_ctx* c);
 // exact.hip
 int gpx_exact_nll_grad(gpx_ctx* c, int cov, const double* hyp, int calc_grad, double* nll, double* grad);
 int gpx_exact_prepare(gpx_ctx* c, int cov, double* hyp);

@@ -268,6 +268,10 @@ struct Sparse {
     // one, buf is produced on `consumer` itself.  Stream-ordered hook: the collective is enqueued on
     // `consumer`, the host never waits.  Host-synchronous hook: wait for buf, call, return when reduced.
     int allreduce(double* buf, long count, hipStream_t consumer, hipEvent_t ready = nullptr) {
+        if (c->rccl_comm) {   // native RCCL: stream-ordered like the hook below, issued by the library itself
+            if (ready) HIP_TRY(hipStreamWaitEvent(consumer, ready, 0));
+            return gpx_rccl_allreduce(c, buf, count, consumer);
+        }
         if (c->allreduce_stream) {
             if (ready) HIP_TRY(hipStreamWaitEvent(consumer, ready, 0));
             return c->allreduce_stream(buf, count, consumer, c->allreduce_user) ? GPX_ERR_STATE : GPX_OK;

@@ -11,4 +11,8 @@ for m in 0:gp 1:fitc 2:vfe; do
   $CXX $FLAGS -DDEMO_MODEL=${m%%:*} -o bin/${m##*:} demos/demo.cpp -L.. -lgpxhost -lgpx -Wl,-rpath,'$ORIGIN/../..'
 done
 $CXX $FLAGS -o bin/facade_check ../../tests/cpp/facade_check.cpp -L.. -lgpxhost -lgpx -Wl,-rpath,'$ORIGIN/../..'
+# programs that own an RCCL communicator (the library itself resolves RCCL at run time and does not link it)
+RCCL="-D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -L/opt/rocm/lib -lrccl -lamdhip64 -Wl,-rpath,/opt/rocm/lib"
+$CXX $FLAGS -fopenmp -o bin/gpx_dist demos/dist_runner.cpp -L.. -lgpxhost -lgpx -Wl,-rpath,'$ORIGIN/../..' $RCCL -lpthread
+$CXX $FLAGS -fopenmp -o bin/rccl_check ../../tests/cpp/rccl_check.cpp -L.. -lgpxhost -lgpx -Wl,-rpath,'$ORIGIN/../..' $RCCL
 echo "built host facade"

@@ -333,8 +333,35 @@ void SparseGP::set_inducing(const MatrixXd& u) {
     _num_inducing = u.cols();
     _inducing_uploaded = false;
 }
+void SparseGP::set_communicator(void* nccl_comm, int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("set_communicator: rank/world");
+    _comm = nccl_comm;
+    _rank = rank;
+    _world = world;
+    _comm_registered = false;
+}
+void SparseGP::time_collectives(bool on) {
+    _upload_inducing();
+    must(gpx_rccl_timing(_ctx, on ? 1 : 0), "rccl_timing");
+}
+double SparseGP::collective_ms(long* count) {
+    _upload_inducing();
+    double ms = 0;
+    int64_t c = 0;
+    must(gpx_rccl_elapsed(_ctx, &ms, &c), "rccl_elapsed");
+    if (count) *count = (long)c;
+    return ms;
+}
+std::pair<long, long> shard_range(long n, int rank, int world) {
+    if (rank < 0 || rank >= world) throw std::invalid_argument("shard_range: rank out of range");
+    return {(long)((long long)n * rank / world), (long)((long long)n * (rank + 1) / world)};
+}
 void SparseGP::_upload_inducing() {
     _upload();
+    if (!_comm_registered) {
+        must(gpx_set_allreduce_rccl(_ctx, _comm), "set_allreduce_rccl");
+        _comm_registered = true;
+    }
     if (_inducing_uploaded) return;
     must(gpx_set_inducing(_ctx, _inducing.data(), (int64_t)_num_inducing), "set_inducing");
     _inducing_uploaded = true;

@@ -133,6 +133,9 @@ protected:
     std::size_t _num_inducing;
     double _jitter_u = 1e-8;
     bool _inducing_uploaded = false;
+    void* _comm = nullptr;   // ncclComm_t of the row-sharded run (set_communicator)
+    int _rank = 0, _world = 1;
+    bool _comm_registered = false;
     double _jitter() const override { return _jitter_u; }
     void _init() override;
     void _setK() override;
@@ -142,6 +145,18 @@ protected:
 
 public:
     void set_inducing(const MatrixXd& u);
+    // Row-sharded evaluation, one process per GPU (no reference counterpart: the reference is single-process; north star
+    // "Kuf.Kfu and diag corrections sharded by training rows ... RCCL all-reduce over xGMI").  THIS object holds the rows
+    // shard_range(n, rank, world) of the training set (the caller constructs it from its shard), the inducing points and
+    // the hypers are the same on every rank; nccl_comm is the caller's ncclComm_t (ncclCommInitRank, one rank per GPU).
+    // The library then issues the two sum-all-reduces of every evaluation (and the one of _setK) itself, on its own
+    // stream; NLL and gradient come out identical on every rank.  Call before the first evaluation or any time after.
+    void set_communicator(void* nccl_comm, int rank, int world);
+    int rank() const { return _rank; }
+    int world() const { return _world; }
+    // device time inside the collectives since the last call (two events around each; enable with time_collectives(true))
+    void time_collectives(bool on);
+    double collective_ms(long* count = nullptr);
     double train(const VectorXd& init_hyps) override;
     using GP::train;
     void test_obj(const VectorXd& hyp);  // prints [hyp, grad, grad_fd] and both timings
@@ -162,6 +177,9 @@ public:
     VFE(const MatrixXd& train_in, const MatrixXd& train_out, CovFunc cf = COV_SE_ARD, MatrixDecomp md = QR)
         : SparseGP(train_in, train_out, cf, md) { _max_eval = 150; }  // VFE.cpp:74
 };
+
+// rows [first, last) of rank's block of n training rows split over world ranks (the same split as gp_amd/sharding.py)
+std::pair<long, long> shard_range(long n, int rank, int world);
 
 // whitespace text matrix IO of the demos (util.cpp:14-62, mygp.cpp:32-36)
 MatrixXd read_matrix(const std::string& path);

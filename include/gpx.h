@@ -115,6 +115,18 @@ int gpx_set_allreduce(gpx_ctx* ctx, gpx_allreduce_fn fn, void* user);
  * flavour clears the other. */
 typedef int (*gpx_allreduce_stream_fn)(double* buf, int64_t count, void* hip_stream, void* user);
 int gpx_set_allreduce_stream(gpx_ctx* ctx, gpx_allreduce_stream_fn fn, void* user);
+/* Native flavour (no reference counterpart; north star "RCCL all-reduce over xGMI of the m x m and m-vector partials"):
+ * the library itself issues ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, nccl_comm, <its stream>) for both
+ * all-reduces of an evaluation and for the one of gpx_prepare, stream-ordered like the hook above.  nccl_comm is an
+ * ncclComm_t created and owned by the caller (one process per GPU, ncclCommInitRank; world size 1 is valid); NULL
+ * unregisters.  libgpx.so does not link librccl: ncclAllReduce is resolved at run time, first in the process (the
+ * library the communicator came from), then from librccl.so.1; returns 4 (unsupported) when neither exists.
+ * gpx_rccl_timing(ctx, 1) brackets every collective with two events on its stream; gpx_rccl_elapsed returns the device
+ * time between them (waiting for peers included) and their count since the last call, and resets both. */
+int gpx_set_allreduce_rccl(gpx_ctx* ctx, void* nccl_comm);
+int gpx_rccl_timing(gpx_ctx* ctx, int on);
+int gpx_rccl_elapsed(gpx_ctx* ctx, double* total_ms, int64_t* collectives);
+const char* gpx_rccl_source(void);
 /* buf *= factor, enqueued on hip_stream (no reference counterpart): lets a test stand in for "R ranks
  * with identical shards" inside a stream-ordered hook, where the all-reduce is a multiplication by R. */
 int gpx_dscal_stream(double* buf, int64_t count, double factor, void* hip_stream);
