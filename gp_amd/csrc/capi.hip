@@ -138,6 +138,18 @@ int gpx_set_allreduce_stream(gpx_ctx* c, gpx_allreduce_stream_fn fn, void* user)
     return GPX_OK;
 }
 
+int gpx_set_spd_check(gpx_ctx* c, int sampled_columns) {
+    if (!c || sampled_columns < 0) return GPX_ERR_ARG;
+    c->spd_check_cols = sampled_columns;
+    return GPX_OK;
+}
+
+int gpx_last_spd_residual(gpx_ctx* c, double* inv_err) {
+    if (!c || !inv_err) return GPX_ERR_ARG;
+    *inv_err = c->last_spd_residual;
+    return GPX_OK;
+}
+
 int gpx_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int calc_grad, double jitter, double* nll,
                  double* grad) {
     if (!c || !hyp || !nll || (calc_grad && !grad)) return GPX_ERR_ARG;

@@ -66,6 +66,9 @@ struct gpx_ctx {
     bool rccl_timing = false;
     std::vector<hipEvent_t> rccl_ev;   // pairs
     size_t rccl_used = 0;
+    // optional residual part of _check_SPD in gpx_prepare (exact model): columns sampled, last value
+    int spd_check_cols = 0;
+    double last_spd_residual = 0.0;
     // state left by gpx_prepare for gpx_predict
     int prepared_model = -1, prepared_cov = 0;
     std::vector<double> prepared_hyp;

@@ -101,6 +101,67 @@ __global__ __launch_bounds__(256) void predict_grad_kernel(long p, int d, const 
 
 const double INF = std::numeric_limits<double>::infinity();
 
+// ---- optional residual part of _check_SPD (GP.cpp:455-456): inv_err = mean |I - K K^-1| ---------------------------
+// unit columns e_col[jj], col[jj] = jj * n / cols
+__global__ void unit_columns_kernel(long n, int cols, double* __restrict__ V, long ldv) {
+    const int jj = blockIdx.x * blockDim.x + threadIdx.x;
+    if (jj < cols) V[(long)jj * n / cols + (long)jj * ldv] = 1.0;
+}
+// slot[0] = sum over the chunk's rows i and the columns jj of | [i0 + i == col[jj]] - (R(i, jj) + sn2 V(i0 + i, jj)) |
+__global__ __launch_bounds__(1024) void spd_residual_kernel(long n, long i0, long tc, int cols, const double* __restrict__ R,
+                                                            long ldr, const double* __restrict__ V, long ldv, double sn2,
+                                                            double* __restrict__ slot) {
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (long e = threadIdx.x; e < tc * cols; e += 1024) {
+        const long i = e % tc, jj = e / tc;
+        const double kk = R[i + jj * ldr] + sn2 * V[i0 + i + jj * ldv];
+        s += fabs(((i0 + i == jj * n / cols) ? 1.0 : 0.0) - kk);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) slot[0] = red[0];
+}
+
+// After a successful factorisation (L in c->A, base-block inverses in c->Wd, scaled inputs in c->Xt): the mean of
+// |e_j - (K + sn2 I) ((K + sn2 I)^-1 e_j)| over `cols` evenly spaced columns j (cols >= n: every column = the
+// reference's mean over all n^2 entries).  K is rebuilt 2048 rows at a time (it was overwritten by its factor), the
+// products run on the matrix cores: 2 triangular solves with `cols` right-hand sides + n x cols x n flops.
+int spd_residual(gpx_ctx* c, const HypView& h, int cols, double* inv_err) {
+    const long n = c->n, ld = gpx_ld(n), chunk = 2048;
+    if (cols > n) cols = (int)n;
+    const long nchunk = (n + chunk - 1) / chunk, ldr = gpx_ld(chunk);
+    int rc;
+    if ((rc = c->pred_K.ensure(ld * cols)) || (rc = c->pred_K2.ensure(ld * chunk)) || (rc = c->pred_g.ensure(ldr * cols)) ||
+        (rc = c->pred_out.ensure(nchunk + 8)))
+        return rc;
+    double* V = c->pred_K.p;
+    HIP_TRY(hipMemsetAsync(V, 0, (size_t)ld * cols * sizeof(double), c->st));
+    hipLaunchKernelGGL(unit_columns_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, c->st, n, cols, V, ld);
+    if ((rc = gpx_trsm_left(c->st, n, cols, c->A.p, c->lda, c->Wd.p, V, ld, 0))) return rc;
+    if ((rc = gpx_trsm_left(c->st, n, cols, c->A.p, c->lda, c->Wd.p, V, ld, 1))) return rc;
+    for (long q = 0; q < nchunk; ++q) {
+        const long i0 = q * chunk, tc = n - i0 < chunk ? n - i0 : chunk;
+        // Kc = k(X, X[i0 : i0 + tc]) (n x tc); R = Kc^T V (tc x cols)
+        if ((rc = gpx_cov_build(c->st, c->Xt.p, c->ldx, n, c->Xt.p + i0, c->ldx, tc, c->dpad, h.sf2, c->pred_K2.p, ld, 0, 0.0)))
+            return rc;
+        if ((rc = gpx_gemm(c->st, 1, 1, tc, cols, n, 1.0, c->pred_K2.p, ld, V, ld, 0.0, c->pred_g.p, ldr, 0))) return rc;
+        hipLaunchKernelGGL(spd_residual_kernel, dim3(1), dim3(1024), 0, c->st, n, i0, tc, cols, c->pred_g.p, ldr, V, ld, h.sn2,
+                           c->pred_out.p + q);
+    }
+    std::vector<double> part(nchunk);
+    HIP_TRY(hipMemcpyAsync(part.data(), c->pred_out.p, nchunk * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    double s = 0;
+    for (double v : part) s += v;
+    *inv_err = s / ((double)n * (double)cols);
+    return GPX_OK;
+}
+
 // K + sn2 I -> A (lower), factor in place, alpha = (K + sn2 I)^-1 (y - mean).  Leaves the device
 // scalars scal[0] = sum log L_ii, scal[1..3] = {r.alpha, sum r, sum alpha}.
 int factor_and_solve(gpx_ctx* c, int cov, const double* hyp, HypView& h) {
@@ -247,7 +308,9 @@ int gpx_exact_nll_grad(gpx_ctx* c, int cov, const double* hyp, int calc_grad, do
 
 // GP::_setK.  SPD policy: the reference's _check_SPD (eigenvalues >= 0, mean|I - K K^-1| < 1e-4,
 // factor OK; GP.cpp:445-461) costs ~5 n^3 extra and is infeasible at n = 65536; here a successful
-// Cholesky (every pivot > 0) is the SPD test, and the noise escalation loop is reproduced as is.
+// Cholesky (every pivot > 0) is the SPD test (a symmetric matrix whose Cholesky succeeds has positive
+// eigenvalues), optionally followed by the residual test on sampled columns (gpx_set_spd_check), and
+// the noise escalation loop is reproduced as is.
 int gpx_exact_prepare(gpx_ctx* c, int cov, double* hyp) {
     if (c->n <= 0) return GPX_ERR_STATE;
     c->prepared_model = -1;
@@ -258,6 +321,11 @@ int gpx_exact_prepare(gpx_ctx* c, int cov, double* hyp) {
         int info = 0;
         HIP_TRY(hipMemcpyAsync(&info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->st));
         HIP_TRY(hipStreamSynchronize(c->st));
+        if (info == 0 && c->spd_check_cols > 0) {
+            // the residual part of _check_SPD (GP.cpp:455-457: inv_err < 1e-4), on sampled columns
+            if ((rc = spd_residual(c, h, c->spd_check_cols, &c->last_spd_residual))) return rc;
+            if (!(c->last_spd_residual < 1e-4)) info = 1;
+        }
         if (info == 0) {
             c->prepared_model = GPX_MODEL_EXACT;
             c->prepared_cov = cov;

@@ -175,7 +175,7 @@ double GP::train(const VectorXd& init_hyps) {
     if (!std::isfinite(nlz)) _hyps = select_init_hyp(_num_hyp * 50, _hyps);
     if (!_fixhyps) {
         std::vector<double> lb = hyp2vec(_hyps_lb), ub = hyp2vec(_hyps_ub), hyp0 = hyp2vec(_hyps);
-        std::unique_ptr<IOptimizer> opt(make_optimizer(hyp0.size()));   // NLopt LD_SLSQP where built in (GP.cpp:231)
+        std::unique_ptr<IOptimizer> opt(_opt_factory ? _opt_factory(hyp0.size()) : make_optimizer(hyp0.size()));   // NLopt LD_SLSQP where built in (GP.cpp:231)
         opt->set_maxeval(_max_eval);
         opt->set_min_objective(&GP::_objective, this);
         opt->set_lower_bounds(lb);
@@ -184,13 +184,20 @@ double GP::train(const VectorXd& init_hyps) {
         _last_evals = r.evals;
         _last_status = r.status + " after " + std::to_string(r.evals) + " evaluations (" + opt->name() + ")";
         _hyps = vec2hyp(hyp0);
+        if (r.status == "FAILURE") _hyps = _after_optimizer_failure(_hyps);   // the catch blocks of GP.cpp:260-265 / VFE.cpp:94-101
     }
     _setK();
     _trained = true;
     return _calcNegLogProb(_hyps);
 }
+double GP::last_spd_residual() const {
+    double v = 0;
+    if (_ctx) must(gpx_last_spd_residual(_ctx, &v), "last_spd_residual");
+    return v;
+}
 void GP::_setK() {
     _upload();
+    must(gpx_set_spd_check(_ctx, _spd_cols), "set_spd_check");
     double jit = 0.0;
     must(gpx_prepare(_ctx, GPX_MODEL_EXACT, _cov->abi_id(), _hyps.data(), &jit), "prepare");
 }

@@ -50,11 +50,17 @@ protected:
     gpx_ctx* _ctx = nullptr;   // created on _device at the first evaluation
     int _device = 0;
     bool _uploaded = false;
+    int _spd_cols = 0;
+    class IOptimizer* (*_opt_factory)(std::size_t) = nullptr;
 
     virtual int _model() const;  // GPX_MODEL_*
     virtual double _jitter() const { return 0.0; }
     virtual void _init();
     virtual void _setK();
+    // what train() does when the optimiser itself fails (nlopt throws std::runtime_error): GP and FITC swallow it and
+    // keep the point reached (GP.cpp:260-265, FITC.cpp:94-100), VFE re-runs the start search with num_hyp * 10
+    // evaluations from that point (VFE.cpp:94-101)
+    virtual VectorXd _after_optimizer_failure(const VectorXd& reached) { return reached; }
     void _upload();
     double _calcNegLogProb(const std::vector<double>&, std::vector<double>& g) const;
     double _calcNegLogProb(const VectorXd& hyp) const;
@@ -89,6 +95,10 @@ public:
     bool noise_free() const { return _noise_free; }
     void set_noise_lower_bound(double) noexcept;
     void set_fixed(bool f) { _fixhyps = f; }
+    // evaluation budget of train() (defaults: 160 / 130 / 150 as GP.cpp:232, FITC.cpp:75, VFE.cpp:74) and the optimiser
+    // behind the seam (default: make_optimizer; tests inject their own)
+    void set_max_eval(int m) { _max_eval = m; }
+    void set_optimizer_factory(class IOptimizer* (*factory)(std::size_t)) { _opt_factory = factory; }
     void set_noise_free(bool flag);
     const std::string& last_optimizer_status() const { return _last_status; }
     int last_optimizer_evals() const { return _last_evals; }
@@ -96,6 +106,10 @@ public:
     // LOCAL_RANK here before the first evaluation
     void set_device(int device);
     int device() const { return _device; }
+    // residual part of _check_SPD (GP.cpp:455-457) inside _setK of the exact GP: mean|I - K K^-1| over `cols` sampled
+    // columns must be < 1e-4, else the noise escalates; 0 (default) = Cholesky success only (see the header comment)
+    void set_spd_check(int cols) { _spd_cols = cols; }
+    double last_spd_residual() const;
     // the optimiser's box (GP.cpp:514-534) and the packing of the hyper vector it sees (GP.cpp:535-564:
     // a noise-free GP drops the noise slot)
     const VectorXd& hyp_lower_bounds() const { return _hyps_lb; }
@@ -172,6 +186,7 @@ public:
 
 class VFE : public SparseGP {
     int _model() const override;
+    VectorXd _after_optimizer_failure(const VectorXd& reached) override { return select_init_hyp(_num_hyp * 10, reached); }   // VFE.cpp:99
 
 public:
     VFE(const MatrixXd& train_in, const MatrixXd& train_out, CovFunc cf = COV_SE_ARD, MatrixDecomp md = QR)

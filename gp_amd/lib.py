@@ -173,6 +173,8 @@ lib.gpx_dscal_stream.argtypes = [_vp, _i64, _d, _vp]
 lib.gpx_nll_grad.argtypes = [_vp, _i, _i, _vp, _i, _d, C.POINTER(_d), _vp]
 lib.gpx_prepare.argtypes = [_vp, _i, _i, _vp, C.POINTER(_d)]
 lib.gpx_predict.argtypes = [_vp, _vp, _i64, _vp, _vp]
+lib.gpx_set_spd_check.argtypes = [_vp, _i]
+lib.gpx_last_spd_residual.argtypes = [_vp, C.POINTER(_d)]
 lib.gpx_predict_with_grad.argtypes = [_vp, _vp, _i64, _vp, _vp, _vp, _vp]
 lib.gpx_cov_k.argtypes = [_i, _i64, _vp, _vp, _i64, _vp, _i64, _vp]
 lib.gpx_chol_solve.argtypes = [_i64, _vp, C.POINTER(_i), C.POINTER(_d), _vp, _i64, _vp]
@@ -247,6 +249,15 @@ class Context:
         j = _d(jitter)
         check(lib.gpx_prepare(self._h, model, cov, hyp.ctypes.data, C.byref(j)), "prepare")
         return hyp, j.value
+
+    def set_spd_check(self, cols):
+        """residual part of _check_SPD (GP.cpp:455-457) inside prepare() of the exact model; 0 = off"""
+        check(lib.gpx_set_spd_check(self._h, int(cols)), "set_spd_check")
+
+    def last_spd_residual(self):
+        v = _d(0.0)
+        check(lib.gpx_last_spd_residual(self._h, C.byref(v)), "last_spd_residual")
+        return v.value
 
     def predict(self, Xs, want_mu=True, want_s2=True):
         Xs = _c(Xs)

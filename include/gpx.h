@@ -144,6 +144,15 @@ int gpx_nll_grad(gpx_ctx* ctx, int model, int cov, const double* hyp, int calc_g
  * escalation, GP.cpp:431-440), jitter is in/out for the sparse models (doubling loops). */
 int gpx_prepare(gpx_ctx* ctx, int model, int cov, double* hyp, double* jitter);
 
+/* The residual part of GP::_check_SPD (GP.cpp:455-457: inv_err = mean|I - K K^-1| < 1e-4) inside gpx_prepare of the
+ * exact model, OFF by default (sampled_columns = 0: a successful Cholesky is the SPD test).  With sampled_columns > 0
+ * the mean is taken over that many evenly spaced columns j of e_j - K (K^-1 e_j) (>= n: all columns, the reference's
+ * exact value); a value >= 1e-4 escalates the noise like a failed pivot (GP.cpp:431-440).  Cost: two triangular solves
+ * with that many right-hand sides + one n x cols x n product on rebuilt rows of K.  The eigenvalue part of _check_SPD
+ * is implied by the Cholesky test. */
+int gpx_set_spd_check(gpx_ctx* ctx, int sampled_columns);
+int gpx_last_spd_residual(gpx_ctx* ctx, double* inv_err);
+
 /* GP::_predict / _predict_y / _predict_s2 (GP.cpp:273-334), FITC (FITC.cpp:109-164), VFE
  * (VFE.cpp:113-131) without input gradients: HOST Xs (d x t); mu and/or s2 may be NULL. */
 int gpx_predict(gpx_ctx* ctx, const double* Xs, int64_t t, double* mu, double* s2);

@@ -7,6 +7,7 @@
 #include <iostream>
 #include <stdexcept>
 #include "../../gp_amd/host/gp.hpp"
+#include "../../gp_amd/host/optimizer.hpp"
 using namespace gpx;
 
 static void pv(const char* k, const VectorXd& v) {
@@ -24,6 +25,7 @@ static void run(const char* tag, M& gp, const VectorXd& init, const MatrixXd& te
     std::snprintf(key, sizeof key, "%s_grad0", tag); pv(key, g);
     std::snprintf(key, sizeof key, "%s_fdrel", tag); std::printf("%s %.17g\n", key, gp.check_gradient(init, 1e-4));
     gp.set_fixed(fixed);
+    if (const char* e = std::getenv("GPX_MAXEVAL")) gp.set_max_eval(std::atoi(e));   // tests: a budget inside which the run converges
     const double nll = gp.train(init);
     std::snprintf(key, sizeof key, "%s_nll", tag); std::printf("%s %.17g\n", key, nll);
     std::fprintf(stderr, "%s optimizer status: %s\n", tag, gp.last_optimizer_status().c_str());
@@ -81,6 +83,34 @@ int main(int argc, char** argv) {
         VectorXd init = gp.get_default_hyps();
         init[init.size() - 2] = std::log(0.1 * stddev(y.data(), n));
         run("vfe", gp, init, test_x, fixed);
+    }
+    {   // VFE::train when the optimiser itself fails (VFE.cpp:94-101): the start search is re-run with num_hyp * 10
+        // evaluations from the point reached; GP / FITC keep that point (GP.cpp:260-265)
+        struct Failing : IOptimizer {
+            const char* name() const override { return "failing test optimiser"; }
+            void set_maxeval(int) override {}
+            void set_min_objective(ObjectiveFn, void*) override {}
+            void set_lower_bounds(const std::vector<double>&) override {}
+            void set_upper_bounds(const std::vector<double>&) override {}
+            OptResult optimize(std::vector<double>&, double&) override { OptResult r; r.status = "FAILURE"; return r; }
+        };
+        auto factory = [](std::size_t) -> IOptimizer* { return new Failing(); };
+        VFE vfe(X, y);
+        vfe.set_inducing(train_x.rightCols(m));
+        VectorXd init = vfe.get_default_hyps();
+        init[init.size() - 2] = std::log(0.1 * stddev(y.data(), n));
+        vfe.set_optimizer_factory(factory);
+        vfe.train(init);
+        const VectorXd want = vfe.select_init_hyp(vfe.num_hyp() * 10, init);
+        bool same = true, moved = false;
+        for (std::size_t i = 0; i < want.size(); ++i) { same = same && want[i] == vfe.get_hyp()[i]; moved = moved || want[i] != init[i]; }
+        FITC fitc(X, y);
+        fitc.set_inducing(train_x.rightCols(m));
+        fitc.set_optimizer_factory(factory);
+        fitc.train(init);
+        bool kept = true;
+        for (std::size_t i = 0; i < init.size(); ++i) kept = kept && fitc.get_hyp()[i] == init[i];
+        std::printf("vfe_failure_fallback %d %d\nfitc_failure_keeps_point %d\n", (int)same, (int)moved, (int)kept);
     }
     {   // seams (1) and (2)
         CovSEiso cov(X.rows());

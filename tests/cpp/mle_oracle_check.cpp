@@ -58,7 +58,8 @@ int main(int argc, char** argv) {
         std::vector<double> none, x = h0;
         const double nll0 = objective(x, none, &p);   // GP.cpp:196
         std::unique_ptr<IOptimizer> opt(make_optimizer(nh));
-        opt->set_maxeval(maxeval[model]);
+        const char* me = std::getenv("GPX_MAXEVAL");   // tests: a budget inside which the run converges, on both sides
+        opt->set_maxeval(me ? std::atoi(me) : maxeval[model]);
         opt->set_min_objective(objective, &p);
         opt->set_lower_bounds(lb);
         opt->set_upper_bounds(ub);

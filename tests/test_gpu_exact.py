@@ -166,3 +166,38 @@ def test_predict_shards_over_test_points(gpx):
             assert np.array_equal(gm_r, gmu[r0:r1]) and np.array_equal(gs_r, gs2[r0:r1])
             ctx.close()
     ref.close()
+
+
+@pytest.mark.parametrize("n,d,ls,lsn", [(200, 2, 1.0, -14.0), (200, 2, 1.5, -16.0), (300, 3, 1.2, -15.0), (150, 1, 0.5, -5.0)])
+def test_setk_residual_spd_check_escalates_like_the_literal_check(gpx, n, d, ls, lsn):
+    """_check_SPD's residual test (GP.cpp:455-457: mean|I - K K^-1| < 1e-4) as the optional flag of gpx_prepare: with
+    nearly singular K + sn2 I every Cholesky pivot is still positive, so the default policy accepts the start noise,
+    while the residual test escalates it (x sqrt(10) per round, GP.cpp:431-440) exactly as far as the oracle's literal
+    _check_SPD does — with all n columns and with 64 sampled ones.  (inv_err within a factor ~2 of the 1e-4 threshold is
+    decided by rounding: e.g. n=150 d=1 l=0.5 log sn=-13 is accepted by the oracle and escalated once here; the cases
+    below are decided the same way on MI355X, measured inv_err at the accepted noise 3.6e-5 .. 5.3e-5; the last one
+    is well conditioned: no escalation on either side.)"""
+    X, y, hyp, Xs = synth.make_problem(8, n, d, 5)
+    hyp[:d] = ls
+    hyp[d + 1] = lsn
+    lit = oracle.ExactState(0, X, y, hyp, literal_spd_check=True)
+    piv = oracle.ExactState(0, X, y, hyp, literal_spd_check=False)
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    h0, _ = ctx.prepare(gpx.MODEL_EXACT, 0, hyp)
+    # default = Cholesky success only: stops earlier than the literal check (at log sn = -16 the matrix is singular to
+    # rounding and whether the last pivot is > 0 depends on the summation order: no equality with the oracle there)
+    assert h0[d + 1] < lit.hyp[d + 1] or lit.hyp[d + 1] == lsn
+    assert lsn > -15.5 and np.array_equal(h0, piv.hyp) or lsn <= -15.5
+    for cols in (n, 64):
+        ctx.set_spd_check(cols)
+        h1, _ = ctx.prepare(gpx.MODEL_EXACT, 0, hyp)
+        print(f"\n[spd check n={n} cols={cols}] log sn {lsn} -> {h1[d + 1]:.6f} (oracle literal {lit.hyp[d + 1]:.6f}), "
+              f"last inv_err {ctx.last_spd_residual():.3e}")
+        assert ctx.last_spd_residual() < 1e-4
+        assert np.allclose(h1, lit.hyp, rtol=0, atol=1e-12)
+        mu, s2 = ctx.predict(Xs)
+        mu_o, s2_o = lit.predict(Xs)
+        # cond(K + sn2 I) ~ 1e13 at the accepted noise: two fp64 solves agree to a few digits only (measured 1e-3)
+        assert np.all(np.isfinite(mu)) and np.max(np.abs(mu - mu_o)) <= 2e-2 * np.max(np.abs(mu_o))
+    ctx.close()

@@ -40,12 +40,27 @@ def test_train_matches_the_oracle_driven_optimisation(tmp_path):
                     "-L" + host, "-lgpxhost", "-lgpx", "-Wl,-rpath," + host, os.path.join(orc, "libgporacle.so"),
                     "-Wl,-rpath," + orc], check=True, timeout=300)
     env = dict(os.environ, GPX_OPTIMIZER="lbfgs")
-    cpu = subprocess.run([exe, str(N), str(M)], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
-    assert cpu.returncode == 0, cpu.stderr
-    gpu = subprocess.run([os.path.join(host, "host", "bin", "facade_check"), str(N), str(M), "0"], cwd=tmp_path,
-                         capture_output=True, text=True, timeout=600, env=env)
-    assert gpu.returncode == 0, gpu.stderr
-    c, q = parse(cpu.stdout), parse(gpu.stdout)
+
+    def both(e):
+        cpu = subprocess.run([exe, str(N), str(M)], cwd=tmp_path, capture_output=True, text=True, timeout=900, env=e)
+        assert cpu.returncode == 0, cpu.stderr
+        gpu = subprocess.run([os.path.join(host, "host", "bin", "facade_check"), str(N), str(M), "0"], cwd=tmp_path,
+                             capture_output=True, text=True, timeout=900, env=e)
+        assert gpu.returncode == 0, gpu.stderr
+        return parse(cpu.stdout), parse(gpu.stdout)
+
+    # (1) a budget inside which every model CONVERGES (the exact GP's 27-parameter ARD search needs more than the
+    # reference's 160 evaluations): the survey's 1e-6 on the final NLL, all three models
+    c, q = both(dict(env, GPX_MAXEVAL="3000"))
+    for tag in ("gp", "fitc", "vfe"):
+        f_c, f_g = c[f"{tag}_nll"][0], q[f"{tag}_nll"][0]
+        print(f"\n[mle converged {tag}] oracle-driven: NLL {f_c:.12g} after {int(c[f'{tag}_evals'][0])} evals "
+              f"({c[f'{tag}_status'][0]}); GPU facade: NLL {f_g:.12g} after {int(q[f'{tag}_evals'][0])} evals; "
+              f"rel diff {abs(f_c - f_g) / abs(f_c):.2e}")
+        assert c[f"{tag}_status"][0] in ("FTOL_REACHED", "XTOL_REACHED"), c[f"{tag}_status"]
+        assert abs(f_c - f_g) <= 1e-6 * abs(f_c)
+    # (2) the reference's own budgets (160 / 130 / 150)
+    c, q = both(env)
     for tag in ("gp", "fitc", "vfe"):
         f_c, f_g = c[f"{tag}_nll"][0], q[f"{tag}_nll"][0]
         e_c, e_g = int(c[f"{tag}_evals"][0]), int(q[f"{tag}_evals"][0])
