@@ -283,7 +283,21 @@ int gpx_exact_nll_grad(gpx_ctx* c, int cov, const double* hyp, int calc_grad, do
     ta.u = c->nalpha.p; ta.v = c->alpha.p;
     ta.sym = 1;
     double* tout = c->scal.p + 16;
-    if ((rc = gpx_pair_trace(c->st, ta, d, c->trace_ws.p, c->trace_ws.cap, tout))) return rc;
+    if (c->mfma_pairwise && gpx_mfma_sym_trace_supported(d)) {
+        // on the matrix cores: r2 from the norm expansion of the centred inputs, the per-dimension sums as a second
+        // contraction (pairwise_mfma.hip); K itself keeps the direct differences (exact sf2 + sn2 diagonal)
+        const long ldxa = gpx_mfma_ldxa(n), ldua = gpx_mfma_ldua(n);
+        const int dk = gpx_mfma_dk(d), n2 = gpx_mfma_n2(d), grid = gpx_mfma_sym_trace_grid(n, d);
+        if ((rc = c->Xa.ensure(dk * ldxa)) || (rc = c->Ua.ensure(dk * ldua)) || (rc = c->UaT.ensure(ldua * n2)) ||
+            (rc = c->cen.ensure(GPX_MAX_DIM)) || (rc = c->spart.ensure((long)grid * (n2 + 2))))
+            return rc;
+        if ((rc = gpx_mfma_prepare(c->st, c->Xt.p, c->ldx, n, c->Xt.p, c->ldx, n, d, c->cen.p, c->Xa.p, c->Ua.p, c->UaT.p))) return rc;
+        if ((rc = gpx_mfma_sym_trace(c->st, c->Xa.p, c->Ua.p, c->UaT.p, n, d, h.sf2, c->A.p, c->lda, c->nalpha.p, c->alpha.p,
+                                     c->spart.p, tout)))
+            return rc;
+    } else if ((rc = gpx_pair_trace(c->st, ta, d, c->trace_ws.p, c->trace_ws.cap, tout))) {
+        return rc;
+    }
     HIP_TRY(hipMemcpyAsync(c->host_scal + 16, tout, (d + 2) * sizeof(double), hipMemcpyDeviceToHost, c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
     const double* S = c->host_scal + 16;

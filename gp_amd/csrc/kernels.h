@@ -49,6 +49,13 @@ int gpx_mfma_cov_build(hipStream_t st, const double* Xa, long n, const double* U
 int gpx_mfma_pair_trace(hipStream_t st, const double* Xa, long n, const double* Ua, const double* UaT, long m, int d, double sf2,
                         const TraceArgs& w, double* cpart, double* spart, double* cvec, double* out);
 
+// the exact GP's trace on the matrix cores: symmetric weights w = M1 + u v^T, M1 valid in its lower triangle, both point
+// sets = the training set (Ua / UaT prepared from the same points as Xa); d <= 30; spart: grid * (n2 + 2) doubles
+bool gpx_mfma_sym_trace_supported(int d);
+int gpx_mfma_sym_trace_grid(long n, int d);
+int gpx_mfma_sym_trace(hipStream_t st, const double* Xa, const double* Ua, const double* UaT, long n, int d, double sf2,
+                       const double* M1, long ldm1, const double* u, const double* v, double* spart, double* out);
+
 // ---- chol.hip -------------------------------------------------------------------------------
 // Blocked recursive lower Cholesky in place (lower triangle of A).  Wd (64 x roundup(n,64),
 // ld 64) receives the inverse of every 64x64 diagonal base block; *info (device int, must be 0

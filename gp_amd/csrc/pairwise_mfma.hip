@@ -596,6 +596,232 @@ __global__ __launch_bounds__(512) void trace_mfma8_kernel(const MfmaPairArgs g) 
     }
 }
 
+
+// ---- the exact GP's gradient trace on the matrix cores: k(X, X) against a SYMMETRIC weight matrix ----------------------
+// w_ab = M1_ab + u_a v_b with M1 = (K + sn2 I)^-1 valid in its lower triangle only (GP.cpp:154-161; exact.hip), both point
+// sets are the training set.  Tiles on and below the diagonal are visited once: an element below the diagonal counts twice
+// (w, K and (x_ia - x_ib)^2 are symmetric), the diagonal once with K_aa = sf2 EXACTLY (r2 forced to 0, as the direct
+// differences of util.cpp:64-75 give it) and elements above it not at all.  Same two contractions as trace_mfma_kernel;
+// the column term  sum_b x~_ib^2 (Q^T 1)_b  is contracted per tile and wave on the vector unit (d multiply-adds per lane and
+// 64-column tile beside 32 exp: 3 %) instead of being written out as n column sums per workgroup.
+// Work unit = (row block of 64 NS rows, chunk of SYM_CT column tiles): the triangle's row blocks differ in length by a
+// factor of n / 128, fixed-size chunks keep the workgroups within a few per cent of one another.
+//   out slots per workgroup (stride N2 + 2): [c < d] S_c, [N2] sum Q, [N2 + 1] tr(w)
+constexpr int SYM_CT = 32;   // column tiles per work unit (2048 columns at TB = 64)
+
+template <int KK, int NS>
+__global__ __launch_bounds__(256, 2) void trace_sym_mfma_kernel(const MfmaPairArgs g, int nunit) {
+    using C = Cfg<KK>;
+    constexpr int JT = C::JT, TB = C::TB, RB = 64 * NS;
+    constexpr int GR = SYM_CT * TB / RB;   // row blocks per chunk width
+    constexpr int DC = 4 * KK - 2;         // dimensions this instantiation can hold (d <= DC)
+    __shared__ __attribute__((aligned(16))) double sU[C::DK * C::S1];
+    __shared__ __attribute__((aligned(16))) double sUT[TB * C::S2];
+    __shared__ double sv[TB];
+    __shared__ double csum[4][TB];
+    __shared__ double red[4][C::N2 + 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int d = g.d;
+    double accS[JT], accC[DC];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) accS[jt] = 0.0;
+#pragma unroll
+    for (int c = 0; c < DC; ++c) accC[c] = 0.0;
+    double accK = 0.0, accT = 0.0;
+    const bool vec = NS == 1 || (((reinterpret_cast<uintptr_t>(g.M1) & 15) == 0) && (g.ldm1 % 2 == 0));
+
+    for (int unit = blockIdx.x; unit < nunit; unit += gridDim.x) {
+        // unit -> (row block blk, chunk ch): row blocks GR a .. GR a + GR - 1 have a + 1 chunks each
+        int a_ = 0;
+        while (GR * (a_ + 1) * (a_ + 2) / 2 <= unit) ++a_;
+        const int o_ = unit - GR * a_ * (a_ + 1) / 2;
+        const int blk = GR * a_ + o_ / (a_ + 1), ch = o_ % (a_ + 1);
+        const long row0 = (long)blk * RB;                       // first row of the block
+        const long a0 = row0 + 16 * NS * wv + NS * l15;         // this lane's NS adjacent rows
+        const long bend = min((long)g.n, row0 + RB);            // columns < bend can be on or below the diagonal
+        const long bfirst = (long)ch * SYM_CT * TB, blast = min(bend, bfirst + (long)SYM_CT * TB);
+        double xf[NS][KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const double* px = g.Xa + (long)(4 * kk + l4) * g.ldxa + a0;
+            if (NS == 2) {
+                const v2d x = *reinterpret_cast<const v2d*>(px);
+                xf[0][kk] = x.x;
+                xf[NS - 1][kk] = x.y;
+            } else {
+                xf[0][kk] = px[0];
+            }
+        }
+        double ua[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) ua[s] = (a0 + s < g.n && g.u) ? g.u[a0 + s] : 0.0;
+        v4d acc2[NS][JT];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) acc2[s][jt] = (v4d){0, 0, 0, 0};
+        const bool rows_in = row0 + RB <= g.n;
+
+        for (long b0 = bfirst; b0 < blast; b0 += TB) {
+            const bool below = b0 + TB <= row0;                  // the whole tile lies strictly below the diagonal
+            const bool full = below && rows_in && vec;
+            __syncthreads();   // the previous tile's fragments are consumed
+            stage_u<KK, true>(g, b0, sU, sUT);
+            if (threadIdx.x < TB) sv[threadIdx.x] = (g.v && b0 + threadIdx.x < g.n) ? g.v[b0 + threadIdx.x] : 0.0;
+            __syncthreads();
+#pragma unroll
+            for (int bt = 0; bt < TB / 16; ++bt) {
+                double w1[4][NS];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long b = b0 + 16 * bt + 4 * r + l4;
+                    const double* p1 = g.M1 + a0 + b * g.ldm1;
+                    if (full) {
+                        if (NS == 2) {
+                            const v2d t = *reinterpret_cast<const v2d*>(p1);
+                            w1[r][0] = t.x;
+                            w1[r][NS - 1] = t.y;
+                        } else {
+                            w1[r][0] = p1[0];
+                        }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) w1[r][s] = (b <= a0 + s && a0 + s < g.n) ? p1[s] : 0.0;   // lower triangle only
+                    }
+                }
+                v4d D[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) D[s] = (v4d){0, 0, 0, 0};
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    const double uf = sU[(4 * kk + l4) * C::S1 + 16 * bt + l15];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) D[s] = mfma(uf, xf[s][kk], D[s]);
+                }
+                double q[NS][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int bl = 16 * bt + 4 * r + l4;
+                    const long b = b0 + bl;
+                    const double vb = sv[bl];
+                    double cs = 0.0;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const long a = a0 + s;
+                        double w = fma(ua[s], vb, w1[r][s]);
+                        double r2 = fmax(D[s][r], 0.0);
+                        if (below) {
+                            w *= 2.0;
+                        } else {
+                            const bool diag = a == b;
+                            if (diag) {
+                                accT += w;
+                                r2 = 0.0;
+                            }
+                            w = (b < a) ? 2.0 * w : (diag ? w : 0.0);
+                            if (a >= g.n) w = 0.0;
+                        }
+                        q[s][r] = w * (g.sf2 * exp_nonpos(-0.5 * r2));
+                        cs += q[s][r];
+                    }
+                    cs = row16_sum(cs);
+                    if (l15 == 0) csum[wv][bl] = cs;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        const double ub = sUT[(16 * bt + 4 * r + l4) * C::S2 + 16 * jt + l15];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) acc2[s][jt] = mfma(q[s][r], ub, acc2[s][jt]);
+                    }
+            }
+            // column term of this wave's rows: lane = column b0 + lane (TB = 64) or b0 + (lane & 31) with the dimensions split
+            // over the two half-waves (TB = 32);  sU[c][b] = -2 x~_cb
+            {
+                const int bl = lane & (TB - 1);
+                const double cs = 0.25 * csum[wv][bl];
+#pragma unroll
+                for (int c = 0; c < DC; ++c) {
+                    if (TB == 32 && ((c & 1) != (lane >> 5))) continue;
+                    const double t = sU[c * C::S1 + bl];
+                    accC[c] = fma(t * t, cs, accC[c]);
+                }
+            }
+        }
+        // end of the unit: acc2[s][jt][r] = row a = base + NS (l4 + 4 r) + s, column c = 16 jt + l15
+        const int jtd = d >> 4, ld = d & 15;   // column d holds (Q 1)_a
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double q1a = 0.0;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+                    if (jt == jtd) q1a = acc2[s][jt][r];
+                q1a = __shfl(q1a, (lane & 48) | ld, 64);
+                const long a = row0 + 16 * NS * wv + NS * (l4 + 4 * r) + s;
+                if (l15 == 0) accK += q1a;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    const int c = 16 * jt + l15;
+                    if (c < d) {
+                        const double x = g.Xa[(long)c * g.ldxa + a];   // zero beyond n
+                        accS[jt] = fma(x, fma(x, q1a, acc2[s][jt][r]), accS[jt]);
+                    }
+                }
+            }
+    }
+    // workgroup partials
+    __syncthreads();
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        double s = accS[jt];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (l4 == 0) red[wv][16 * jt + l15] = s;
+    }
+    {
+        double s = accK, t = accT;
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);   // accK lives in the lanes with l15 == 0, accT anywhere
+            t += __shfl_xor(t, o, 64);
+        }
+        if (lane == 0) {
+            red[wv][C::N2] = s;
+            red[wv][C::N2 + 1] = t;
+        }
+    }
+    __syncthreads();
+    // the column terms: sum over the lanes, added to the row terms of the same dimension
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+        double s = accC[c];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0 && c < d) red[wv][c] += s;
+    }
+    __syncthreads();
+    if (threadIdx.x < C::N2 + 2)
+        g.spart[(long)blockIdx.x * (C::N2 + 2) + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// out[i < d] = sum_wg spart[wg][i];  out[d] = sum Q;  out[d + 1] = tr(w)
+__global__ void trace_sym_finish_kernel(const double* __restrict__ spart, int nwg, int n2, int d, double* __restrict__ out) {
+    __shared__ double red[256];
+    const int i = blockIdx.x;
+    const int col = i < d ? i : (i == d ? n2 : n2 + 1);
+    double s = 0.0;
+    for (int w = threadIdx.x; w < nwg; w += 256) s += spart[(long)w * (n2 + 2) + col];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[i] = red[0];
+}
+
 // ---- operand preparation ----------------------------------------------------------------------------
 // cen[i] = mean over the m inducing points of the scaled coordinate i
 __global__ void centre_kernel(const double* __restrict__ Ut, long ldu, long m, double* __restrict__ cen) {
@@ -820,6 +1046,46 @@ int gpx_mfma_pair_trace(hipStream_t st, const double* Xa, long n, const double* 
     }
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((g.ldua + 31) / 32)), dim3(256), 0, st, cpart, grid, g.ldua, cvec);
     hipLaunchKernelGGL(trace_mfma_finish_kernel, dim3(d + 1), dim3(256), 0, st, spart, grid, n2, Ua, g.ldua, m, cvec, d, out);
+    gpx_pair_prof_close(st, slot);
+    HIP_TRY(hipGetLastError());
+    return GPX_OK;
+}
+
+// The exact GP's trace (symmetric weights, both point sets = the training set): d <= 30 (two 16-row tiles per wave).
+bool gpx_mfma_sym_trace_supported(int d) { return d >= 1 && kk_of(d) <= 8; }
+int gpx_mfma_sym_trace_grid(long n, int d) {
+    (void)d;
+    const long nblk = (n + 127) / 128, gr = SYM_CT * 64 / 128;
+    const long a = nblk / gr, b = nblk % gr;
+    const long units = gr * a * (a + 1) / 2 + b * (a + 1);
+    return (int)(units < 1024 ? units : 1024);   // 2 resident workgroups per CU x 2 rounds of units in flight
+}
+// Xa, Ua, UaT from gpx_mfma_prepare(st, Xt, ldx, n, Xt, ldx, n, ...); M1 valid in its lower triangle; w = M1 + u v^T;
+// spart: grid * (N2 + 2) doubles.  out[0..d-1] = S_i, out[d] = sum w K, out[d+1] = tr(w)  (as gpx_pair_trace with sym = 1)
+int gpx_mfma_sym_trace(hipStream_t st, const double* Xa, const double* Ua, const double* UaT, long n, int d, double sf2,
+                       const double* M1, long ldm1, const double* u, const double* v, double* spart, double* out) {
+    if (n <= 0 || !gpx_mfma_sym_trace_supported(d)) return GPX_ERR_ARG;
+    MfmaPairArgs g = {};
+    g.Xa = Xa; g.ldxa = gpx_mfma_ldxa(n); g.n = n;
+    g.Ua = Ua; g.ldua = gpx_mfma_ldua(n); g.m = n;
+    g.UaT = UaT;
+    g.d = d; g.sf2 = sf2;
+    g.M1 = M1; g.ldm1 = ldm1;
+    g.u = u; g.v = v;
+    g.spart = spart;
+    const long nblk = (n + 127) / 128, gr = SYM_CT * 64 / 128;
+    const long a = nblk / gr, b = nblk % gr;
+    const long units = gr * a * (a + 1) / 2 + b * (a + 1);
+    if (units > 0x3fffffffL) return GPX_ERR_ARG;
+    const int grid = gpx_mfma_sym_trace_grid(n, d), n2 = gpx_mfma_n2(d);
+    const long slot = gpx_pair_prof_open(st, 1, 4.0 * (double)n * (double)n);
+    switch (kk_of(d)) {
+#define GPX_SYM_CASE(K) case K: hipLaunchKernelGGL((trace_sym_mfma_kernel<K, 2>), dim3(grid), dim3(256), 0, st, g, (int)units); break;
+        GPX_SYM_CASE(1) GPX_SYM_CASE(2) GPX_SYM_CASE(3) GPX_SYM_CASE(4) GPX_SYM_CASE(5) GPX_SYM_CASE(6) GPX_SYM_CASE(7)
+        default: hipLaunchKernelGGL((trace_sym_mfma_kernel<8, 2>), dim3(grid), dim3(256), 0, st, g, (int)units); break;
+#undef GPX_SYM_CASE
+    }
+    hipLaunchKernelGGL(trace_sym_finish_kernel, dim3(d + 2), dim3(256), 0, st, spart, grid, n2, d, out);
     gpx_pair_prof_close(st, slot);
     HIP_TRY(hipGetLastError());
     return GPX_OK;
