@@ -36,6 +36,8 @@ int gpx_ctx_create(int device, gpx_ctx** out) {
     {
         const char* e = getenv("GPX_NO_MFMA_PAIRWISE");
         c->mfma_pairwise = !(e && e[0] == '1');
+        e = getenv("GPX_NO_PANELS");
+        c->panels = !(e && e[0] == '1');
         e = getenv("GPX_FITC_NO_WHITEN");
         c->fitc_whiten = !(e && e[0] == '1');
     }

@@ -73,6 +73,17 @@ int gpx_dgemm_rowdot(int64_t M, int64_t N, int64_t K, double alpha, const double
     return gpx_gemm_rowdot(0, 0, 0, M, N, K, alpha, A, lda, B, ldb, C, ldc, flags, rd);
 }
 
+// measurement / test entry (not in gpx.h): the split-K product with BOTH operands K-contiguous and row-panelled
+int gpx_dgemm_splitk_panelled(int64_t M, int64_t N, int64_t K, double alpha, const double* A, const double* B, int64_t pan, int64_t pst,
+                              double beta, double* C, int64_t ldc, int flags, double* work, int64_t work_doubles, const double* kscale) {
+    GemmPanels pn = {};
+    pn.panA = pn.panB = pan; pn.pstA = pn.pstB = pst;
+    return gpx_gemm_splitk(0, 1, 1, M, N, K, alpha, A, pan, B, pan, beta, C, ldc, flags, work, work_doubles, kscale, &pn);
+}
+int64_t gpx_dgemm_splitk_panel_rows(int64_t M, int64_t N, int64_t K, int flags, int64_t work_doubles) {
+    return gpx_gemm_splitk_panel_rows(M, N, K, flags, work_doubles);
+}
+
 int gpx_dscal_stream(double* buf, int64_t count, double factor, void* hip_stream) {
     if (!buf || count < 0) return GPX_ERR_ARG;
     return gpx_vec_shift(static_cast<hipStream_t>(hip_stream), count, buf, 0.0, factor, buf);

@@ -54,6 +54,7 @@ struct gpx_ctx {
     // matrix-core pairwise path (pairwise_mfma.hip): centred, augmented operands and its partial sums
     DevBuf Xa, Ua, UaT, cen, cpart, spart, cvec;
     DevBuf rowp1, rowp2;  // FITC: per-64-column partial row sums written by the GEMM row-dot epilogue [2 ceil(m/128)][ldn]
+    bool panels = true;          // GPX_NO_PANELS=1: the n x m matrices of the sparse models plain column-major (A/B)
     bool fitc_whiten = true;     // GPX_FITC_NO_WHITEN=1: the reference's A = sn2 Kuu + Kux G^-1 Kxu instead of M = sn2 I + V^T G^-1 V (A/B)
     bool mfma_pairwise = true;   // GPX_NO_MFMA_PAIRWISE=1 keeps the vector-unit kernels (A/B runs, fallback tests)
     // all-reduce hook for row-sharded FITC/VFE

@@ -47,6 +47,13 @@ struct GemmArgs : TileOrder {
     const double* E; long lde;
     const double* evec;
     double* R1; double* R2; long ldr;
+    // Row-panel layout of the tall n x m matrices of the sparse models (see GemmPanels in gpx_internal.h): the CONTIGUOUS
+    // index c of an operand (m for an M-contiguous A / C / E, n for an N-contiguous B, k for a K-contiguous A / B) is cut
+    // into panels of pan rows, element (c, s) lives at (c / pan) * pst + c % pan + s * ld.  A workgroup never leaves a
+    // panel (pan is a multiple of 128; K-panelled products are split-K with kper K tiles = one panel per slab), so one
+    // base-pointer shift per workgroup, (c / pan) * (pst - pan), makes every address formula below valid as it stands.
+    long panA, pstA, panB, pstB, panC, pstC, panE, pstE;
+    int kper;   // K tiles per split-K slab (0: ceil(K tiles / slabs))
 };
 
 // Offset of a wave's j-th 16-column group inside the block tile, relative to the wave's base column.  With four groups per
@@ -61,12 +68,12 @@ __device__ __forceinline__ constexpr int sub16(int i) { return T == 4 ? (i & 1) 
 // slot among the 2 * ceil(N / 128) row-dot parts
 // RD == 1: E = C (row sums of squares, R1 only); RD == 2: E, evec, R1 and R2 all given
 template <int TM, int TN, bool FULL, int RD>
-__device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const v4d (&acc)[TN][TM], int mb, int nb, int part, int l15, int l4) {
+__device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const double* gE, const v4d (&acc)[TN][TM], int mb, int nb, int part, int l15, int l4) {
     double s1[TM], s2[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) s1[i] = s2[i] = 0.0;
     // one running pointer per operand (the 16 i offsets are immediates): no per-element 64-bit address registers
-    const double* ep = (RD == 2 && FULL) ? g.E + (mb + l15) + (long)(nb + l4) * g.lde : nullptr;
+    const double* ep = (RD == 2 && FULL) ? gE + (mb + l15) + (long)(nb + l4) * g.lde : nullptr;
     const double* vp = (RD == 2 && FULL) ? g.evec + nb + l4 : nullptr;
     const long estep = 4 * g.lde;
 #pragma unroll
@@ -85,7 +92,7 @@ __device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const v4d (&a
                 } else {   // edge tiles: clamped addresses and 0/1 masks instead of guarded loads (no divergent branches)
                     const int n = nb + sub16<TN>(j) + l4 + 4 * r;
                     const double nmask = n < g.N ? 1.0 : 0.0;
-                    const double* col = g.E + (long)min(n, g.N - 1) * g.lde;
+                    const double* col = gE + (long)min(n, g.N - 1) * g.lde;
                     ev = g.evec[min(n, g.N - 1)] * nmask;
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
@@ -129,11 +136,11 @@ __device__ __forceinline__ void rowdot_epilogue(const GemmArgs& g, const v4d (&a
 // are stored while they are in flight, then the two row dots are formed (separate store and dot passes leave the
 // matrix pipe idle for 64 load round trips in 8 batches per tile: Cu GEMM 29.8 -> 32.2 ms at n = 2^20)
 template <int TM, int TN>
-__device__ __forceinline__ void store_rowdot_full(const GemmArgs& g, const v4d (&acc)[TN][TM], double* Cb, int mb, int nb, int part, int l15, int l4) {
+__device__ __forceinline__ void store_rowdot_full(const GemmArgs& g, const double* gE, const v4d (&acc)[TN][TM], double* Cb, int mb, int nb, int part, int l15, int l4) {
     double s1[TM], s2[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) s1[i] = s2[i] = 0.0;
-    const double* ep = g.E + (mb + l15) + (long)(nb + l4) * g.lde;
+    const double* ep = gE + (mb + l15) + (long)(nb + l4) * g.lde;
     const double* vp = g.evec + nb + l4;
     double* cp = Cb + (mb + l15) + (long)(nb + l4) * g.ldc;
     const long estep = 4 * g.lde, cstep = 4 * g.ldc;
@@ -267,10 +274,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     int nkt = khi > klo ? (khi - klo + BK - 1) / BK : 0;
     int kt0 = 0, kt1 = nkt;
     if (g.splitk > 1) {
-        const int per = (nkt + g.splitk - 1) / g.splitk;
+        const int per = g.kper ? g.kper : (nkt + g.splitk - 1) / g.splitk;
         kt0 = min(nkt, ks * per);
         kt1 = min(nkt, kt0 + per);
     }
+
+    // row-panel layout: one base shift per workgroup and operand (see GemmArgs)
+    const double* gA = g.A;
+    const double* gB = g.B;
+    double* gC = g.C;
+    const double* gE = g.E;
+    if (g.panA) gA += (long)((AKC ? klo + kt0 * BK : m0) / g.panA) * (g.pstA - g.panA);
+    if (g.panB) gB += (long)((BKC ? klo + kt0 * BK : n0) / g.panB) * (g.pstB - g.panB);
+    if (g.panC) gC += (long)(m0 / g.panC) * (g.pstC - g.panC);
+    if (g.panE) gE += (long)(m0 / g.panE) * (g.pstE - g.panE);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave & 1) * (16 * TM), wn = (wave >> 1) * (TN == 4 ? 32 : 16 * TN);   // see sub16
@@ -305,8 +322,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const bool down = __builtin_amdgcn_readfirstlane(desc);
         const long k00 = klo + (down ? kt1 - 1 : kt0) * BK;
-        const char* pa = reinterpret_cast<const char*>(g.A) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
-        const char* pb = reinterpret_cast<const char*>(g.B) + (BKC ? k00 + (long)n0 * g.ldb : n0 + k00 * g.ldb) * 8;
+        const char* pa = reinterpret_cast<const char*>(gA) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
+        const char* pb = reinterpret_cast<const char*>(gB) + (BKC ? k00 + (long)n0 * g.ldb : n0 + k00 * g.ldb) * 8;
         const long ka = (AKC ? (long)BK : BK * g.lda) * (down ? -8 : 8), kb = (BKC ? (long)BK : BK * g.ldb) * (down ? -8 : 8);
         // wave-load q = wv + 4 i (i = 0..3): M-contiguous -> k-row q; K-contiguous -> rows 8q .. 8q+7
         const long ia = (AKC ? 32 * g.lda : 4 * g.lda) * 8, ib = (BKC ? 32 * g.ldb : 4 * g.ldb) * 8;
@@ -369,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         // RD == 2: the epilogue reads the 128 x 128 tile of E in four batches per wave, one L2-miss round trip each.
         // With the loads of the LAST K tile, every thread touches four of the tile's 1024 lines (4-byte direct-to-LDS
         // loads into the dummy word, as the operand warm-up), two K tiles before the epilogue needs them.
-        const char* pe = RD == 2 ? reinterpret_cast<const char*>(g.E) + ((long)m0 + (long)n0 * g.lde) * 8 : nullptr;
+        const char* pe = RD == 2 ? reinterpret_cast<const char*>(gE) + ((long)m0 + (long)n0 * g.lde) * 8 : nullptr;
         const unsigned eoff = (unsigned)(((tid & 7) * 16 + (long)(tid >> 3) * g.lde) * 8);   // 16-row chunk, column tid / 8
         auto warm_e = [&]() {
 #pragma unroll
@@ -487,8 +504,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         // operand registers are a ring of TWO K tiles: the loads of tile kt + 2 are issued while tile kt is multiplied
         // (measured 0.75 us per K step with a one-tile distance, i.e. 0.3 us of exposed latency per step).
         const long k00 = klo + kt0 * BK;
-        const char* pa = reinterpret_cast<const char*>(g.A) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
-        const char* pb = reinterpret_cast<const char*>(g.B) + (BKC ? k00 + (long)n0 * g.ldb : n0 + k00 * g.ldb) * 8;
+        const char* pa = reinterpret_cast<const char*>(gA) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
+        const char* pb = reinterpret_cast<const char*>(gB) + (BKC ? k00 + (long)n0 * g.ldb : n0 + k00 * g.ldb) * 8;
         const long ia = (AKC ? (NT / 8) * g.lda : (2 * NT / BM) * g.lda) * 8;  // between a thread's consecutive loads
         const long ib = (BKC ? (NT / 8) * g.ldb : (2 * NT / BN) * g.ldb) * 8;
         const long ka = (AKC ? (long)BK : BK * g.lda) * 8;            // per K tile
@@ -557,8 +574,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
     } else if (interior) {
         const long k00 = klo + kt0 * BK;
-        const char* pa = reinterpret_cast<const char*>(g.A) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
-        const char* pb = reinterpret_cast<const char*>(g.B) + (BKC ? k00 + (long)n0 * g.ldb : n0 + k00 * g.ldb) * 8;
+        const char* pa = reinterpret_cast<const char*>(gA) + (AKC ? k00 + (long)m0 * g.lda : m0 + k00 * g.lda) * 8;
+        const char* pb = reinterpret_cast<const char*>(gB) + (BKC ? k00 + (long)n0 * g.ldb : n0 + k00 * g.ldb) * 8;
         const long ia = (AKC ? (NT / 8) * g.lda : (2 * NT / BM) * g.lda) * 8;  // between a thread's consecutive loads
         const long ib = (BKC ? (NT / 8) * g.ldb : (2 * NT / BN) * g.ldb) * 8;
         const long ka = (AKC ? (long)BK : BK * g.lda) * 8;            // per K tile
@@ -622,8 +639,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         if (kt0 < kt1) {
             const int k0 = klo + kt0 * BK;
             const bool kin = k0 + BK <= g.K;
-            gload<BM, AKC, NT>(g.A, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
-            gload<BN, BKC, NT>(g.B, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
+            gload<BM, AKC, NT>(gA, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
+            gload<BN, BKC, NT>(gB, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
             if (scaled) scale_tile(k0);
         }
         for (int kt = kt0; kt < kt1; ++kt) {
@@ -634,8 +651,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             if (kt + 1 < kt1) {
                 const int k0 = klo + (kt + 1) * BK;
                 const bool kin = k0 + BK <= g.K;
-                gload<BM, AKC, NT>(g.A, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
-                gload<BN, BKC, NT>(g.B, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
+                gload<BM, AKC, NT>(gA, g.lda, m0, k0, g.M, g.K, tfA && kin, ra);
+                gload<BN, BKC, NT>(gB, g.ldb, n0, k0, g.N, g.K, tfB && kin, rb);
                 if (scaled) scale_tile(k0);
             }
 #pragma unroll
@@ -655,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
 
     // epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4) + 4r]
-    double* Cb = g.C + (g.splitk > 1 ? (long)ks * g.slab : 0);
+    double* Cb = gC + (g.splitk > 1 ? (long)ks * g.slab : 0);
     const bool plain = RD != 0 || g.splitk > 1 || g.beta == 0.0;   // the row-dot variants are beta == 0 only: no old-value path in them
     if (RD == 3 && bj == 0) {
         if (dot_done) {   // the two waves of a row half hold the same sums: one of them writes
@@ -670,14 +687,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             const int m = m0 + tid;
             if (tid < BM && m < g.M) {
                 double a = 0.0;
-                for (int k = 0; k < g.K; ++k) a = fma(AKC ? g.A[k + (long)m * g.lda] : g.A[m + (long)k * g.lda], g.evec[k], a);
+                for (int k = 0; k < g.K; ++k) a = fma(AKC ? gA[k + (long)m * g.lda] : gA[m + (long)k * g.lda], g.evec[k], a);
                 g.R2[m] = a;
             }
         }
     }
     const int part = 2 * bj + (wave >> 1);   // row-dot parts: two per tile column (one per wave column)
     if (RD == 2 && m0 + BM <= g.M && n0 + BN <= g.N) {
-        store_rowdot_full<TM, TN>(g, acc, Cb, m0 + wm, n0 + wn, part, l15, l4);
+        store_rowdot_full<TM, TN>(g, gE, acc, Cb, m0 + wm, n0 + wn, part, l15, l4);
         return;
     }
     if (m0 + BM <= g.M && n0 + BN <= g.N) {
@@ -705,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                     for (int i = 0; i < TM; ++i) cj[r * s4 + 16 * i] = g.alpha * acc[j][i][r] + g.beta * old[r][i];
             }
         }
-        if (RD == 1 || RD == 2) rowdot_epilogue<TM, TN, true, RD>(g, acc, m0 + wm, n0 + wn, part, l15, l4);
+        if (RD == 1 || RD == 2) rowdot_epilogue<TM, TN, true, RD>(g, gE, acc, m0 + wm, n0 + wn, part, l15, l4);
         return;
     }
 #pragma unroll
@@ -723,7 +740,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
                 }
             }
         }
-    if (RD == 1 || RD == 2) rowdot_epilogue<TM, TN, false, RD>(g, acc, m0 + wm, n0 + wn, part, l15, l4);   // a part without columns gets zeros
+    if (RD == 1 || RD == 2) rowdot_epilogue<TM, TN, false, RD>(g, gE, acc, m0 + wm, n0 + wn, part, l15, l4);   // a part without columns gets zeros
 }
 
 __global__ void splitk_reduce_kernel(double* __restrict__ C, long ldc, const double* __restrict__ W,
@@ -784,8 +801,22 @@ double useful_flops(long M, long N, long K, int flags) {
 
 int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
               const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
-              int flags, int splitk, double* work, const double* kscale = nullptr, const GemmRowdot* rd = nullptr) {
+              int flags, int splitk, double* work, const double* kscale = nullptr, const GemmRowdot* rd = nullptr,
+              const GemmPanels* pn = nullptr) {
     if (M <= 0 || N <= 0) return GPX_OK;
+    int kper = 0;
+    if (pn) {
+        for (long v : {pn->panA, pn->panB, pn->panC, pn->panE})
+            if (v < 0 || v % 128) return GPX_ERR_ARG;   // a tile never straddles two panels
+        const long kpan = (a_kc && pn->panA) ? pn->panA : ((b_kc && pn->panB) ? pn->panB : 0);
+        if (kpan) {
+            // K-panelled operand(s): one panel per split-K slab, full K range of every tile
+            if ((a_kc && b_kc && pn->panA != pn->panB) || (flags & (GEMM_KLO_M | GEMM_KLO_N | GEMM_KHI_M | GEMM_KHI_N))) return GPX_ERR_ARG;
+            kper = (int)(kpan / BK);
+            const long need = (K + kpan - 1) / kpan;
+            if (need > 1 && splitk != need) return GPX_ERR_ARG;   // gpx_gemm_splitk derives the slab count from the panels
+        }
+    }
     const bool opdot = rd && !rd->R1 && !rd->E && rd->evec && rd->R2;   // R2 = A evec from the operand fragments
     if (opdot) {
         if (a_kc || b_kc || beta != 0.0 || splitk > 1 || (flags & (GEMM_LOWER | GEMM_TILE64 | GEMM_KLO_M | GEMM_KHI_M | GEMM_KLO_N | GEMM_KHI_N))) return GPX_ERR_ARG;
@@ -813,8 +844,13 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
     if (rd && (rd->R1 || opdot)) {
         g.E = rd->E; g.lde = rd->lde; g.evec = rd->evec; g.R1 = rd->R1; g.R2 = rd->R2; g.ldr = rd->ldr;
     }
-    g.fastA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 2 == 0);
-    g.fastB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 2 == 0);
+    g.panA = pn ? pn->panA : 0; g.pstA = pn ? pn->pstA : 0;
+    g.panB = pn ? pn->panB : 0; g.pstB = pn ? pn->pstB : 0;
+    g.panC = pn ? pn->panC : 0; g.pstC = pn ? pn->pstC : 0;
+    g.panE = pn ? pn->panE : 0; g.pstE = pn ? pn->pstE : 0;
+    g.kper = kper;
+    g.fastA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 2 == 0) && (!pn || pn->pstA % 2 == 0);
+    g.fastB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 2 == 0) && (!pn || pn->pstB % 2 == 0);
     const TilePlan plan = plan_tiles(M, N, flags, splitk, kscale != nullptr);
     static_cast<TileOrder&>(g) = plan.main;
     if (!gemm_lane_offsets_fit_32bit(lda, a_kc != 0) || !gemm_lane_offsets_fit_32bit(ldb, b_kc != 0)) g.flags |= GEMM_NO_FAST32;
@@ -967,20 +1003,42 @@ int gpx_mfma_peak(double* tflops) {
 
 int gpx_gemm(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
              const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
-             int flags) {
-    return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, 1, nullptr);
+             int flags, const GemmPanels* pn) {
+    return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, 1, nullptr, nullptr, nullptr, pn);
 }
 
 int gpx_gemm_rowdot(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha, const double* A, long lda,
-                    const double* B, long ldb, double* C, long ldc, int flags, const GemmRowdot& rd) {
-    return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, 0.0, C, ldc, flags, 1, nullptr, nullptr, &rd);
+                    const double* B, long ldb, double* C, long ldc, int flags, const GemmRowdot& rd, const GemmPanels* pn) {
+    return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, 0.0, C, ldc, flags, 1, nullptr, nullptr, &rd, pn);
+}
+
+// slab count and tile size of a split-K product (flags gains GEMM_TILE128 where 128-tiles pay)
+static int choose_splitk(long M, long N, long K, int& flags, long work_doubles);
+
+// rows per panel of the K-contiguous operands of a split-K Gram product over K = n rows: the K range of one slab of the
+// slab count the product would take anyway, rounded up to a multiple of 128 rows
+long gpx_gemm_splitk_panel_rows(long M, long N, long K, int flags, long work_doubles) {
+    int f = flags;
+    const int sk = choose_splitk(M, N, K, f, work_doubles);
+    const long kt = (K + BK - 1) / BK, per = (kt + sk - 1) / sk;
+    return (per + 7) / 8 * 128;
 }
 
 int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
                     const double* A, long lda, const double* B, long ldb, double beta, double* C,
-                    long ldc, int flags, double* work, long work_doubles, const double* kscale) {
+                    long ldc, int flags, double* work, long work_doubles, const double* kscale, const GemmPanels* pn) {
+    int splitk = work ? choose_splitk(M, N, K, flags, work_doubles) : 1;
+    const long kpan = pn ? ((a_kc && pn->panA) ? pn->panA : ((b_kc && pn->panB) ? pn->panB : 0)) : 0;
+    if (kpan) {   // K-panelled operands: one panel per slab
+        splitk = (int)((K + kpan - 1) / kpan);
+        if (splitk > 1 && (!work || (long)splitk * M * N > work_doubles)) return GPX_ERR_ARG;
+    }
+    return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, splitk, work, kscale, nullptr, pn);
+}
+
+static int choose_splitk(long M, long N, long K, int& flags, long work_doubles) {
     int splitk = 1;
-    if (work) {
+    {
         const long kt = (K + BK - 1) / BK;
         // 128x128 tiles (twice the flops per operand byte) whenever enough slabs fit the workspace to
         // fill the chip with them; 64x64 tiles otherwise
@@ -1014,5 +1072,5 @@ int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, 
                 splitk *= 2;
         }
     }
-    return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, splitk, work, kscale);
+    return splitk;
 }

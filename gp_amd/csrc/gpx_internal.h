@@ -42,16 +42,26 @@ static inline long gpx_ld(long n) {
 //   b_kc == 0: B(n,k) at B[n + k*ldb] (N-contiguous);  b_kc == 1: B(n,k) at B[k + n*ldb]
 // flags:
 #include "gemm_flags.h"
+// Row-panel layout of the tall n x m matrices of the sparse models (Kxu, V, B, C): the n rows are cut into panels of
+// `pan` rows (a multiple of 128), element (a, b) lives at (a / pan) * pst + a % pan + b * ld with ld = pan, pst >= pan * m.
+// A column of a panel is pan * 8 bytes from the next (150 KB) instead of n * 8 (8 MB): the K-contiguous operand tiles of
+// the Gram products Kux G Kxu (128 columns x 16 rows per K step) touch ~10 pages instead of 128.  pan = 0: plain
+// column-major.  Per operand: the panelled index is its CONTIGUOUS one (m for A when !a_kc, k when a_kc; C and E: m).
+struct GemmPanels {
+    long panA, pstA, panB, pstB, panC, pstC, panE, pstE;
+};
 int gpx_gemm(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
              const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
-             int flags);
+             int flags, const GemmPanels* pn = nullptr);
 // split-K variant for short-and-wide outputs (K >> M,N): partial slabs in `work`
 // (>= splitk*M*N doubles), then a deterministic reduction.  work may be NULL -> plain gemm.
 // kscale (optional, K-contiguous A only, 16-B aligned): C = alpha * op(A) diag(kscale) op(B)^T + beta*C,
 // the weighted Gram products K^T diag(g) K of the sparse models without a scaled copy of K.
 int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
                     const double* A, long lda, const double* B, long ldb, double beta, double* C,
-                    long ldc, int flags, double* work, long work_doubles, const double* kscale = nullptr);
+                    long ldc, int flags, double* work, long work_doubles, const double* kscale = nullptr,
+                    const GemmPanels* pn = nullptr);
+long gpx_gemm_splitk_panel_rows(long M, long N, long K, int flags, long work_doubles);
 
 // C = alpha op(A) op(B)^T (128-tiles, no split-K) with a row-dot epilogue: per part p (64 columns) of the output
 //   R1[p*ldr + m] = sum_{n in part p} C(m,n) * E(m,n)     (E == NULL: E = C, the row sums of squares)
@@ -64,7 +74,7 @@ struct GemmRowdot {
     double* R1; double* R2; long ldr;
 };
 int gpx_gemm_rowdot(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha, const double* A, long lda,
-                    const double* B, long ldb, double* C, long ldc, int flags, const GemmRowdot& rd);
+                    const double* B, long ldb, double* C, long ldc, int flags, const GemmRowdot& rd, const GemmPanels* pn = nullptr);
 
 // per-launch HIP-event timing of GEMM launches with >= min_flops useful flops (bench.py roofline)
 int gpx_gemm_prof_begin(double min_flops, int max_launches);

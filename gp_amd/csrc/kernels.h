@@ -43,11 +43,12 @@ int gpx_mfma_trace_grid(long n, int d, long m, bool two_weight_matrices);
 // centred, augmented operands from the scaled dimension-major inputs; Xa may be NULL (U side only)
 int gpx_mfma_prepare(hipStream_t st, const double* Xt, long ldx, long n, const double* Ut, long ldu, long m, int d,
                      double* cen, double* Xa, double* Ua, double* UaT);
+// pan / pst: row-panel layout of out and of the weight matrices M1 / M2 (GemmPanels in gpx_internal.h; 0 = plain)
 int gpx_mfma_cov_build(hipStream_t st, const double* Xa, long n, const double* Ua, long m, int d, double sf2, double* out,
-                       long ldo);
+                       long ldo, long pan = 0, long pst = 0);
 // weights from w (M1/c1, M2/c2, u/v); cpart: grid*ldua doubles, spart: grid*(n2+1), cvec: ldua
 int gpx_mfma_pair_trace(hipStream_t st, const double* Xa, long n, const double* Ua, const double* UaT, long m, int d, double sf2,
-                        const TraceArgs& w, double* cpart, double* spart, double* cvec, double* out);
+                        const TraceArgs& w, double* cpart, double* spart, double* cvec, double* out, long pan = 0, long pst = 0);
 
 // the exact GP's trace on the matrix cores: symmetric weights w = M1 + u v^T, M1 valid in its lower triangle, both point
 // sets = the training set (Ua / UaT prepared from the same points as Xa); d <= 30; spart: grid * (n2 + 2) doubles
@@ -83,5 +84,6 @@ int gpx_logdiag_sum(hipStream_t st, long n, const double* A, long lda, double* o
 // tri = 1: A is lower triangular (entries above the diagonal are skipped)
 int gpx_gemv_n(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
                double beta, double* y, int tri = 0);
+// pan / pst: the M rows of A in row panels (GemmPanels in gpx_internal.h; 0 = plain; not with tri)
 int gpx_gemv_t(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
-               double beta, double* y, int tri = 0);
+               double beta, double* y, int tri = 0, long pan = 0, long pst = 0);

@@ -44,7 +44,12 @@ struct MfmaPairArgs {
     double* cpart;   // [gridDim][ldua] column sums of Q per workgroup (zero on entry)
     double* spart;   // [gridDim][N2 + 1]
     int nblk;        // row blocks of the trace kernel (128 or 64 rows)
+    // row-panel layout of out / M1 / M2 (GemmPanels in gpx_internal.h): rows in panels of pan (a multiple of 128, 0 = plain),
+    // element (a, b) at (a / pan) * pst + a % pan + b * ld; a row block never straddles two panels
+    long pan, pst;
 };
+// base shift of the row block that starts at row a0 (see MfmaPairArgs::pan)
+__device__ __forceinline__ long panel_shift(const MfmaPairArgs& g, long a0) { return g.pan ? (a0 / g.pan) * (g.pst - g.pan) : 0; }
 
 template <int KK>
 struct Cfg {
@@ -131,7 +136,8 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_kernel(const MfmaPairArgs g) 
         xf[1][kk] = x.y;
     }
     const bool rows_in = (long)blockIdx.x * 128 + 128 <= g.n;
-    const bool vec = ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (g.ldo % 2 == 0);
+    double* const outb = g.out + panel_shift(g, (long)blockIdx.x * 128);
+    const bool vec = ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (g.ldo % 2 == 0) && (g.pst % 2 == 0);
     for (long b0 = 0; b0 < g.m; b0 += C::TB) {
         __syncthreads();
         stage_u<KK, false>(g, b0, sU, nullptr);
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_kernel(const MfmaPairArgs g) 
                 const long b = b0 + 16 * bt + 4 * r + l4;
                 const double k0 = g.sf2 * exp_nonpos(-0.5 * fmax(D0[r], 0.0));
                 const double k1 = g.sf2 * exp_nonpos(-0.5 * fmax(D1[r], 0.0));
-                double* o = g.out + a0 + b * g.ldo;
+                double* o = outb + a0 + b * g.ldo;
                 if (full) {
                     *reinterpret_cast<v2d*>(o) = (v2d){k0, k1};
                 } else if (b < g.m) {
@@ -185,11 +191,14 @@ __global__ __launch_bounds__(256, 2) void trace_mfma_kernel(const MfmaPairArgs g
     for (int jt = 0; jt < JT; ++jt) accS[jt] = 0.0;
     double accK = 0.0;
     double* cp = g.cpart + (long)blockIdx.x * g.ldua;
-    const bool vec = NS == 1 || (((reinterpret_cast<uintptr_t>(g.M1) & 15) == 0) && (g.ldm1 % 2 == 0) &&
+    const bool vec = NS == 1 || (((reinterpret_cast<uintptr_t>(g.M1) & 15) == 0) && (g.ldm1 % 2 == 0) && (g.pst % 2 == 0) &&
                                  (!HAS_M2 || (((reinterpret_cast<uintptr_t>(g.M2) & 15) == 0) && (g.ldm2 % 2 == 0))));
 
     for (int blk = blockIdx.x; blk < g.nblk; blk += gridDim.x) {
         const long a0 = (long)blk * RB + 16 * NS * wv + NS * l15;   // this lane's NS adjacent rows in the r2 tiles
+        const long psh = panel_shift(g, (long)blk * RB);
+        const double* const M1b = g.M1 + psh;
+        const double* const M2b = HAS_M2 ? g.M2 + psh : nullptr;
         double xf[NS][KK];
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void trace_mfma_kernel(const MfmaPairArgs g
 #pragma unroll
                 for (int i = 0; i < TB / 4; ++i) {
                     const long b = b0 + 4 * i + l4;   // i = 4 bt + r
-                    wpf[i] = (full || (b < g.m && a0 < g.n)) ? g.M1[a0 + b * g.ldm1] : 0.0;
+                    wpf[i] = (full || (b < g.m && a0 < g.n)) ? M1b[a0 + b * g.ldm1] : 0.0;
                 }
             }
             __syncthreads();   // the previous tile's fragments are consumed, its column sums are in csum
@@ -247,8 +256,8 @@ __global__ __launch_bounds__(256, 2) void trace_mfma_kernel(const MfmaPairArgs g
                         continue;
                     }
                     const long b = b0 + 16 * bt + 4 * r + l4;
-                    const double* p1 = g.M1 + a0 + b * g.ldm1;
-                    const double* p2 = HAS_M2 ? g.M2 + a0 + b * g.ldm2 : nullptr;
+                    const double* p1 = M1b + a0 + b * g.ldm1;
+                    const double* p2 = HAS_M2 ? M2b + a0 + b * g.ldm2 : nullptr;
                     if (full) {
                         if (NS == 2) {
                             const v2d t = *reinterpret_cast<const v2d*>(p1);
@@ -426,8 +435,9 @@ __global__ __launch_bounds__(512) void trace_mfma8_kernel(const MfmaPairArgs g) 
     auto load_w = [&](int blk, int tl, double (&w1)[TB / 4], double (&w2)[TB / 4]) {
         const int b0 = tl * TB;
         const long a = (long)blk * RB + 16 * wv + l15;
-        const double* s1 = g.M1 + (long)blk * RB + (long)b0 * g.ldm1;   // wave-uniform
-        const double* s2 = HAS_M2 ? g.M2 + (long)blk * RB + (long)b0 * g.ldm2 : nullptr;
+        const long psh = panel_shift(g, (long)blk * RB);
+        const double* s1 = g.M1 + psh + (long)blk * RB + (long)b0 * g.ldm1;   // wave-uniform
+        const double* s2 = HAS_M2 ? g.M2 + psh + (long)blk * RB + (long)b0 * g.ldm2 : nullptr;
         if ((long)blk * RB + RB <= g.n && b0 + TB <= m) {   // wave-uniform: the interior takes no per-load guard
 #pragma unroll
             for (int i = 0; i < TB / 4; ++i) {
@@ -998,9 +1008,11 @@ int gpx_mfma_prepare(hipStream_t st, const double* Xt, long ldx, long n, const d
 }
 
 int gpx_mfma_cov_build(hipStream_t st, const double* Xa, long n, const double* Ua, long m, int d, double sf2, double* out,
-                       long ldo) {
+                       long ldo, long pan, long pst) {
     if (n <= 0 || m <= 0) return GPX_OK;
+    if (pan % 128) return GPX_ERR_ARG;
     MfmaPairArgs g = {};
+    g.pan = pan; g.pst = pst;
     g.Xa = Xa; g.ldxa = gpx_mfma_ldxa(n); g.n = n;
     g.Ua = Ua; g.ldua = gpx_mfma_ldua(m); g.m = m;
     g.d = d; g.sf2 = sf2; g.out = out; g.ldo = ldo;
@@ -1015,9 +1027,10 @@ int gpx_mfma_cov_build(hipStream_t st, const double* Xa, long n, const double* U
 
 // out[0..d-1] = S_i, out[d] = sum W K, out[d+1] = 0.  cpart: grid * ldua doubles, spart: grid * (N2 + 1), cvec: ldua.
 int gpx_mfma_pair_trace(hipStream_t st, const double* Xa, long n, const double* Ua, const double* UaT, long m, int d, double sf2,
-                        const TraceArgs& w, double* cpart, double* spart, double* cvec, double* out) {
-    if (n <= 0 || m <= 0) return GPX_ERR_ARG;
+                        const TraceArgs& w, double* cpart, double* spart, double* cvec, double* out, long pan, long pst) {
+    if (n <= 0 || m <= 0 || pan % 128) return GPX_ERR_ARG;
     MfmaPairArgs g = {};
+    g.pan = pan; g.pst = pst;
     g.Xa = Xa; g.ldxa = gpx_mfma_ldxa(n); g.n = n;
     g.Ua = Ua; g.ldua = gpx_mfma_ldua(m); g.m = m;
     g.UaT = UaT;

@@ -212,6 +212,19 @@ struct Sparse {
     long n, m, ldn, ldm;
     int d, model, cov;
     HypView h;
+    // Row-panel layout of the n x m matrices Kxu, V, B, C (GemmPanels in gpx_internal.h): pan rows per panel = the K range
+    // of one split-K slab of the Gram products, so that their K-contiguous operand columns are pan * 8 bytes apart (150 KB)
+    // instead of n * 8 (8 MB): probe 20.9 -> 17.0 ms at n = 2^20, m = 1024 (tools/probe/gram_panel_probe.py).  pan = 0 (one
+    // panel would do, the vector-unit fallback kernels, GPX_NO_PANELS=1): plain column-major with leading dimension ldn.
+    long pan = 0, pst = 0, ldk = 0;   // ldk: leading dimension of the n x m matrices (pan or ldn)
+    GemmPanels pn_of(bool a, bool b, bool cc, bool e) const {
+        GemmPanels p = {};
+        if (a) { p.panA = pan; p.pstA = pst; }
+        if (b) { p.panB = pan; p.pstB = pst; }
+        if (cc) { p.panC = pan; p.pstC = pst; }
+        if (e) { p.panE = pan; p.pstE = pst; }
+        return p;
+    }
 
     bool mfma() const { return c->mfma_pairwise && gpx_mfma_pair_supported(d); }
     long nparts() const { return 2 * ((m + 127) / 128); }   // parts of the GEMM row-dot epilogue (gpx_internal.h)
@@ -219,7 +232,8 @@ struct Sparse {
     int v_and_gamma(const double* Winv_u, const double* r, double sn2, double sf2, double* g, double* p) {
         GemmRowdot rd = {};
         rd.R1 = c->rowp1.p; rd.ldr = ldn;
-        int rc = gpx_gemm_rowdot(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, Winv_u, ldm, c->V.p, ldn, GEMM_KHI_N, rd);
+        const GemmPanels pn = pn_of(true, false, true, false);
+        int rc = gpx_gemm_rowdot(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldk, Winv_u, ldm, c->V.p, ldk, GEMM_KHI_N, rd, &pn);
         if (rc) return rc;
         hipLaunchKernelGGL(fitc_gamma_kernel, dim3(nblk(n)), dim3(256), 0, st, n, (int)nparts(), c->rowp1.p, ldn, r, sn2, sf2, g, p,
                            part());
@@ -229,6 +243,16 @@ struct Sparse {
         int rc;
         ldn = gpx_ld(n);
         ldm = gpx_ld(m);
+        const long tcap = gpx_trtri_scratch(m) > 64 * ldm * m ? gpx_trtri_scratch(m) : 64 * ldm * m;   // trtri scratch / split-K slabs
+        pan = pst = 0;
+        ldk = ldn;
+        if (mfma() && c->panels) {
+            const long R = gpx_gemm_splitk_panel_rows(m, m, n, GEMM_LOWER, tcap);
+            if (R < n) {
+                pan = ldk = R;
+                pst = R * m + (R * m) % 2;
+            }
+        }
         if (mfma()) {
             const long ldxa = gpx_mfma_ldxa(n), ldua = gpx_mfma_ldua(m);
             const int dk = gpx_mfma_dk(d), n2 = gpx_mfma_n2(d), grid = std::max(gpx_mfma_trace_grid(n, d, m, false), gpx_mfma_trace_grid(n, d, m, true));
@@ -237,7 +261,7 @@ struct Sparse {
                 return rc;
             if (grad && ((rc = c->cpart.ensure((long)grid * ldua)) || (rc = c->spart.ensure((long)grid * (n2 + 1))))) return rc;
         }
-        const long nm = ldn * m, mm = ldm * m;
+        const long nm = pan ? (n + pan - 1) / pan * pst : ldn * m, mm = ldm * m;
         if ((rc = c->Kxu.ensure(nm))) return rc;
         if (model == GPX_MODEL_FITC) {
             if ((rc = c->V.ensure(nm)) || (rc = c->rowp1.ensure(nparts() * ldn))) return rc;
@@ -250,7 +274,7 @@ struct Sparse {
             if ((rc = b->ensure(mm))) return rc;
         const long wdn = 64L * ((m + 63) / 64 * 64);
         if ((rc = c->Wd_u.ensure(wdn)) || (rc = c->Wd_A.ensure(wdn))) return rc;
-        if ((rc = c->T.ensure(gpx_trtri_scratch(m) > 64 * mm ? gpx_trtri_scratch(m) : 64 * mm))) return rc;  // trtri scratch / split-K slabs
+        if ((rc = c->T.ensure(tcap))) return rc;
         for (int i = 0; i < 8; ++i)
             if ((rc = c->vn[i].ensure(n)) || (rc = c->vm[i].ensure(m + 80))) return rc;  // + 64: direct-to-LDS loads read whole 32-entry tiles
         if ((rc = c->red.ensure(m * m + m + GPX_MAX_DIM + 96))) return rc;
@@ -307,14 +331,14 @@ struct Sparse {
         if (mfma()) {
             if ((rc = gpx_mfma_prepare(st, c->Xt.p, c->ldx, n, c->Ut.p, c->ldu, m, d, c->cen.p, c->Xa.p, c->Ua.p, c->UaT.p)))
                 return rc;
-            return gpx_mfma_cov_build(st, c->Xa.p, n, c->Ua.p, m, d, h.sf2, c->Kxu.p, ldn);
+            return gpx_mfma_cov_build(st, c->Xa.p, n, c->Ua.p, m, d, h.sf2, c->Kxu.p, ldk, pan, pst);
         }
         return gpx_cov_build(st, c->Xt.p, c->ldx, n, c->Ut.p, c->ldu, m, c->dpad, h.sf2, c->Kxu.p, ldn, 0, 0.0);
     }
     // sum_ab W_ab dKxu_ab/dtheta for every kernel hyper in one pass (weights in ta)
     int trace_xu(const TraceArgs& ta, double* out) {
         if (mfma())
-            return gpx_mfma_pair_trace(st, c->Xa.p, n, c->Ua.p, c->UaT.p, m, d, h.sf2, ta, c->cpart.p, c->spart.p, c->cvec.p, out);
+            return gpx_mfma_pair_trace(st, c->Xa.p, n, c->Ua.p, c->UaT.p, m, d, h.sf2, ta, c->cpart.p, c->spart.p, c->cvec.p, out, pan, pst);
         return gpx_pair_trace(st, ta, d, c->trace_ws.p, c->trace_ws.cap, out);
     }
     // inputs, Kuu (+jitter on its diagonal) factored into Lu, Kxu
@@ -374,8 +398,10 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     if (rc) return rc;
     if ((rc = s.alloc(calc_grad != 0))) return rc;
     const HypView& h = s.h;
-    const long n = s.n, m = s.m, ldn = s.ldn, ldm = s.ldm;
+    const long n = s.n, m = s.m, ldn = s.ldn, ldm = s.ldm, ldk = s.ldk;
+    const GemmPanels pnK = s.pn_of(true, true, false, false);   // Gram products: both operands K-contiguous over the n rows
     const int d = s.d, nh = h.nk + 2;
+    (void)ldn;
     hipStream_t st = c->st;  // main stream; phase 2 switches to the side stream
     const bool fitc = model == GPX_MODEL_FITC;
     // reduction buffer [F (m, padded to 16) | S (m*m) | tail]: all-reduce #1 takes F, S and the first tail entries,
@@ -415,25 +441,26 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         // (this HBM-bound GEMV on the side stream, beside the matrix-pipe-bound Gram product below, was measured: the Gram
         // product loses more than the GEMV's 1.65 ms, 113.4 -> 114.9 ms per evaluation)
         // whitened form (default): F_v = V^T Gamma^-1 r = Lu^-1 F;  else F = Kux Gamma^-1 r (FITC.cpp:218)
-        if ((rc = gpx_gemv_t(st, n, m, 1.0, gram_op, ldn, p, 0.0, redF))) return rc;
+        if ((rc = gpx_gemv_t(st, n, m, 1.0, gram_op, ldk, p, 0.0, redF, 0, s.pan, s.pst))) return rc;
     } else {
         hipLaunchKernelGGL(vfe_rstats_kernel, dim3(nblk(n)), dim3(256), 0, st, n, c->r.p, s.part());
         s.finish_partials(n, redT, 3);  // r^T r, -, n_local
-        if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, c->r.p, 0.0, redF))) return rc;  // F = Kux r
+        if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldk, c->r.p, 0.0, redF, 0, s.pan, s.pst))) return rc;  // F = Kux r
     }
     // S = Kux [Gamma^-1] Kxu, lower tiles, split-K over the training rows (FITC.cpp:217, VFE.cpp:173)
     // (F = Kux [Gamma^-1] r as an operand dot of THIS product - from the A fragments of its first tile column, partial sums
     // per split-K slab, as Kxu a leaves the product Kxu P below - was written and measured: the tiles that carry the dot
     // fall behind the other tiles of their slab and the slab loses its shared L2 reads; the Gram product grows by more
     // than the GEMV it replaces, FITC 113.25 -> 113.6 ms, VFE 846 -> 866 ms, same box; not kept.)
-    if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, gram_op, ldn, gram_op, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
-                              fitc ? g : nullptr)))
+    if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, gram_op, ldk, gram_op, ldk, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
+                              fitc ? g : nullptr, &pnK)))
         return rc;
     HIP_TRY(hipEventRecord(c->ev[0], st));
     if (fitc && calc_grad) {
         // B = Kxu Kuu^-1 = V Lu^-1 (FITC.cpp:214) does not depend on A: it keeps the GPU full while the
         // all-reduce and the (narrow) factor chain of A run beside it
-        if ((rc = gpx_gemm(st, 0, 1, n, m, m, 1.0, c->V.p, ldn, c->Winv_u.p, ldm, 0.0, c->Bm.p, ldn, GEMM_KLO_N))) return rc;
+        const GemmPanels pn = s.pn_of(true, false, true, false);
+        if ((rc = gpx_gemm(st, 0, 1, n, m, m, 1.0, c->V.p, ldk, c->Winv_u.p, ldm, 0.0, c->Bm.p, ldk, GEMM_KLO_N, &pn))) return rc;
     }
     if ((rc = s.allreduce(redF, mp + m * m + 16, c->st2, c->ev[0]))) return rc;
 
@@ -524,8 +551,9 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         // C = Gamma^-1 Kxu A^-1 (FITC.cpp:262) and B = Kxu Kuu^-1 = V Lu^-1 (FITC.cpp:214)
         double* Cm = c->Cm.p;  // Cu = Kxu A^-1; C = diag(1/Gamma) Cu enters through per-row coefficients
         GemmRowdot rd = {};   // rowsum(Cu o Kxu) and Kxu a leave the GEMM with Cu
-        rd.E = c->Kxu.p; rd.lde = ldn; rd.evec = a_vec; rd.R1 = c->rowp1.p; rd.R2 = c->rowp2.p; rd.ldr = ldn;
-        if ((rc = gpx_gemm_rowdot(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->A_inv.p, ldm, Cm, ldn, 0, rd))) return rc;
+        rd.E = c->Kxu.p; rd.lde = ldk; rd.evec = a_vec; rd.R1 = c->rowp1.p; rd.R2 = c->rowp2.p; rd.ldr = s.ldn;
+        const GemmPanels pnC = s.pn_of(true, false, true, true);
+        if ((rc = gpx_gemm_rowdot(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldk, c->A_inv.p, ldm, Cm, ldk, 0, rd, &pnC))) return rc;
         double* c2coef = c->vn[3].p;
         double* ucoef = c->vn[4].p;
         double* wv = c->vn[5].p;
@@ -533,13 +561,13 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
                            g, p, h.sn2, c2coef, ucoef, wv, s.part());
         s.finish_partials(n, redT + GPX_MAX_DIM + 8, 4);  // sum(g-c1), sum pq^2, sum pq, sum w
         // half of W_xu = C - (1/sn2) pq a^T - (1/sn2) diag(w) B, contracted with every dKxu at once
-        ta.M1 = Cm; ta.ldm1 = ldn; ta.c1 = g;
-        ta.M2 = c->Bm.p; ta.ldm2 = ldn; ta.c2 = c2coef;
+        ta.M1 = Cm; ta.ldm1 = ldk; ta.c1 = g;
+        ta.M2 = c->Bm.p; ta.ldm2 = ldk; ta.c2 = c2coef;
         ta.u = ucoef;
         if ((rc = s.trace_xu(ta, redT))) return rc;
         // B^T diag(w) B: w (signed) is the K-dimension scale of the lower-tile split-K product
-        if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Bm.p, ldn, c->Bm.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
-                                  wv)))
+        if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Bm.p, ldk, c->Bm.p, ldk, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
+                                  wv, &pnK)))
             return rc;
         if ((rc = s.allreduce(red, m * m + GPX_MAX_DIM + 32, st))) return rc;
         hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, red, m);
@@ -555,11 +583,12 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         // (the GEMV took 13 ms of 841 at n = 2^22, m = 2048)
         GemmRowdot rd = {};
         rd.evec = a_vec; rd.R2 = Ka;
-        if ((rc = gpx_gemm_rowdot(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldn, c->Wuu.p, ldm, c->Cm.p, ldn, 0, rd))) return rc;
+        const GemmPanels pnC = s.pn_of(true, false, true, false);
+        if ((rc = gpx_gemm_rowdot(st, 0, 0, n, m, m, 1.0, c->Kxu.p, ldk, c->Wuu.p, ldm, c->Cm.p, ldk, 0, rd, &pnC))) return rc;
         double* nalpha = c->vn[3].p;
         hipLaunchKernelGGL(vfe_alpha_kernel, dim3(nblk(n)), dim3(256), 0, st, n, c->r.p, Ka, h.sn2, nalpha, s.part());
         s.finish_partials(n, redT + GPX_MAX_DIM + 8, 2);  // sum alpha^2, sum alpha
-        ta.M1 = c->Cm.p; ta.ldm1 = ldn;
+        ta.M1 = c->Cm.p; ta.ldm1 = ldk;
         ta.u = nalpha;
         if ((rc = s.trace_xu(ta, redT))) return rc;
         // tr(A^-1 S) and G = Kuu^-1 S Kuu^-1 use the reduced S (still in red[0..m*m), symmetrised)
@@ -622,7 +651,8 @@ int gpx_sparse_prepare(gpx_ctx* c, int model, int cov, const double* hyp, double
     if (rc) return rc;
     if ((rc = s.alloc(false))) return rc;
     const HypView& h = s.h;
-    const long n = s.n, m = s.m, ldn = s.ldn, ldm = s.ldm;
+    const long n = s.n, m = s.m, ldm = s.ldm, ldk = s.ldk;
+    const GemmPanels pnK = s.pn_of(true, true, false, false);
     hipStream_t st = c->st;
     const bool fitc = model == GPX_MODEL_FITC;
     const long mp = (m + 15) / 16 * 16;   // [F | S] as in gpx_sparse_nll_grad
@@ -644,14 +674,14 @@ int gpx_sparse_prepare(gpx_ctx* c, int model, int cov, const double* hyp, double
         if (fitc) {
             if ((rc = s.inverse(c->Lu.p, c->Wd_u.p, c->Winv_u.p, nullptr, true))) return rc;
             if ((rc = s.v_and_gamma(c->Winv_u.p, c->r.p, h.sn2, h.sf2, c->vn[0].p, c->vn[1].p))) return rc;
-            if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, c->vn[1].p, 0.0, redF))) return rc;
-            if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Kxu.p, ldn, c->Kxu.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p,
-                                      c->T.cap, c->vn[0].p)))
+            if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldk, c->vn[1].p, 0.0, redF, 0, s.pan, s.pst))) return rc;
+            if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Kxu.p, ldk, c->Kxu.p, ldk, 0.0, red, m, GEMM_LOWER, c->T.p,
+                                      c->T.cap, c->vn[0].p, &pnK)))
                 return rc;
         } else {
-            if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldn, c->r.p, 0.0, redF))) return rc;
-            if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Kxu.p, ldn, c->Kxu.p, ldn, 0.0, red, m, GEMM_LOWER, c->T.p,
-                                      c->T.cap)))
+            if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldk, c->r.p, 0.0, redF, 0, s.pan, s.pst))) return rc;
+            if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Kxu.p, ldk, c->Kxu.p, ldk, 0.0, red, m, GEMM_LOWER, c->T.p,
+                                      c->T.cap, nullptr, &pnK)))
                 return rc;
         }
         if (mp > m) HIP_TRY(hipMemsetAsync(redF + m, 0, (mp - m) * sizeof(double), st));

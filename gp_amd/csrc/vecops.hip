@@ -61,45 +61,50 @@ __global__ __launch_bounds__(64 * GEMV_NW) void gemv_n_kernel(long M, long K, do
     }
 }
 
-// y[j] = beta*y[j] + alpha * sum_i A[i + j*lda] x[i]; one wave per column
+// y[j] = beta*y[j] + alpha * sum_i A[i + j*lda] x[i]; one wave per column.  pan > 0: the M rows live in row panels of pan
+// rows (element (i, j) at (i / pan) * pst + i % pan + j * lda): the column is walked panel by panel.
 __global__ __launch_bounds__(256) void gemv_t_kernel(long M, long K, double alpha, const double* __restrict__ A,
                                                      long lda, const double* __restrict__ x, double beta,
-                                                     double* __restrict__ y, int tri) {
+                                                     double* __restrict__ y, int tri, long pan, long pst) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long j = (long)blockIdx.x * 4 + w;
     if (j >= K) return;
-    const double* a = A + j * lda;
     double s0 = 0.0, s1 = 0.0;
-    long i0 = tri ? j : 0;  // lower triangular: rows >= column
-    if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(x)) & 15) == 0) {
-        // long columns (the n x m products of the sparse models have only m of them): 16-B loads, eight
-        // of them in flight per lane, so that one wave per column still covers the HBM latency
-        if (i0 & 1) {
-            if (l == 0) s0 = a[i0] * x[i0];
-            ++i0;
+    const long step = pan ? pan : M;
+    for (long r0 = 0; r0 < M; r0 += step) {
+        const double* a = A + j * lda + (pan ? (r0 / pan) * pst - r0 : 0);   // a[i] = element (i, j) for r0 <= i < r1
+        const long r1 = r0 + step < M ? r0 + step : M;
+        long i0 = tri ? j : r0;  // lower triangular: rows >= column
+        if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(x)) & 15) == 0) {
+            // long columns (the n x m products of the sparse models have only m of them): 16-B loads, eight
+            // of them in flight per lane, so that one wave per column still covers the HBM latency
+            if (i0 & 1) {
+                if (l == 0) s0 = fma(a[i0], x[i0], s0);
+                ++i0;
+            }
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            const long nchunk = r1 > i0 ? (r1 - i0) / 512 : 0;  // 512 rows per wave and step
+            for (long c = 0; c < nchunk; ++c) {
+                const long i = i0 + 512 * c + 2 * l;
+                const v2d a0 = *reinterpret_cast<const v2d*>(a + i), a1 = *reinterpret_cast<const v2d*>(a + i + 128);
+                const v2d a2 = *reinterpret_cast<const v2d*>(a + i + 256), a3 = *reinterpret_cast<const v2d*>(a + i + 384);
+                const v2d x0 = *reinterpret_cast<const v2d*>(x + i), x1 = *reinterpret_cast<const v2d*>(x + i + 128);
+                const v2d x2 = *reinterpret_cast<const v2d*>(x + i + 256), x3 = *reinterpret_cast<const v2d*>(x + i + 384);
+                t0 = fma(a0.x, x0.x, fma(a0.y, x0.y, t0));
+                t1 = fma(a1.x, x1.x, fma(a1.y, x1.y, t1));
+                t2 = fma(a2.x, x2.x, fma(a2.y, x2.y, t2));
+                t3 = fma(a3.x, x3.x, fma(a3.y, x3.y, t3));
+            }
+            s0 += (t0 + t1) + (t2 + t3);
+            for (long r = i0 + 512 * nchunk + l; r < r1; r += 64) s1 = fma(a[r], x[r], s1);
+        } else {
+            long i = l + i0;
+            for (; i + 64 < r1; i += 128) {
+                s0 = fma(a[i], x[i], s0);
+                s1 = fma(a[i + 64], x[i + 64], s1);
+            }
+            for (; i < r1; i += 64) s0 = fma(a[i], x[i], s0);
         }
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-        const long nchunk = M > i0 ? (M - i0) / 512 : 0;  // 512 rows per wave and step
-        for (long c = 0; c < nchunk; ++c) {
-            const long i = i0 + 512 * c + 2 * l;
-            const v2d a0 = *reinterpret_cast<const v2d*>(a + i), a1 = *reinterpret_cast<const v2d*>(a + i + 128);
-            const v2d a2 = *reinterpret_cast<const v2d*>(a + i + 256), a3 = *reinterpret_cast<const v2d*>(a + i + 384);
-            const v2d x0 = *reinterpret_cast<const v2d*>(x + i), x1 = *reinterpret_cast<const v2d*>(x + i + 128);
-            const v2d x2 = *reinterpret_cast<const v2d*>(x + i + 256), x3 = *reinterpret_cast<const v2d*>(x + i + 384);
-            t0 = fma(a0.x, x0.x, fma(a0.y, x0.y, t0));
-            t1 = fma(a1.x, x1.x, fma(a1.y, x1.y, t1));
-            t2 = fma(a2.x, x2.x, fma(a2.y, x2.y, t2));
-            t3 = fma(a3.x, x3.x, fma(a3.y, x3.y, t3));
-        }
-        s0 += (t0 + t1) + (t2 + t3);
-        for (long r = i0 + 512 * nchunk + l; r < M; r += 64) s1 = fma(a[r], x[r], s1);
-    } else {
-        long i = l + i0;
-        for (; i + 64 < M; i += 128) {
-            s0 = fma(a[i], x[i], s0);
-            s1 = fma(a[i + 64], x[i + 64], s1);
-        }
-        for (; i < M; i += 64) s0 = fma(a[i], x[i], s0);
     }
     double s = s0 + s1;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -117,9 +122,10 @@ int gpx_gemv_n(hipStream_t st, long M, long K, double alpha, const double* A, lo
 }
 
 int gpx_gemv_t(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
-               double beta, double* y, int tri) {
+               double beta, double* y, int tri, long pan, long pst) {
     if (K <= 0) return GPX_OK;
+    if (pan && (tri || pan % 2 || pst % 2)) return GPX_ERR_ARG;
     hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, st, M, K, alpha, A, lda, x, beta,
-                       y, tri);
+                       y, tri, pan, pst);
     return GPX_OK;
 }
