@@ -617,13 +617,23 @@ __global__ __launch_bounds__(512) void trace_mfma8_kernel(const MfmaPairArgs g) 
 // Work unit = (row block of 64 NS rows, chunk of SYM_CT column tiles): the triangle's row blocks differ in length by a
 // factor of n / 128, fixed-size chunks keep the workgroups within a few per cent of one another.
 //   out slots per workgroup (stride N2 + 2): [c < d] S_c, [N2] sum Q, [N2 + 1] tr(w)
-constexpr int SYM_CT = 32;   // column tiles per work unit (2048 columns at TB = 64)
+// gr = row blocks per chunk width (a chunk = gr * RB columns): 16 (2048 columns) for large n, less where that would leave
+// fewer units than resident workgroups (n = 8192: 160 units of 32 tiles took 327 us, 2080 units of 2 tiles take a third)
+inline long sym_units(long nblk, long gr) {
+    const long a = nblk / gr, b = nblk % gr;
+    return gr * a * (a + 1) / 2 + b * (a + 1);
+}
+inline int sym_gr(long nblk) {
+    int gr = 16;
+    while (gr > 1 && sym_units(nblk, gr) < 2048) gr /= 2;
+    return gr;
+}
 
 template <int KK, int NS>
-__global__ __launch_bounds__(256, 2) void trace_sym_mfma_kernel(const MfmaPairArgs g, int nunit) {
+__global__ __launch_bounds__(256, 2) void trace_sym_mfma_kernel(const MfmaPairArgs g, int nunit, int GR) {
     using C = Cfg<KK>;
     constexpr int JT = C::JT, TB = C::TB, RB = 64 * NS;
-    constexpr int GR = SYM_CT * TB / RB;   // row blocks per chunk width
+    const int SYM_CT = GR * RB / TB;       // column tiles per work unit
     constexpr int DC = 4 * KK - 2;         // dimensions this instantiation can hold (d <= DC)
     __shared__ __attribute__((aligned(16))) double sU[C::DK * C::S1];
     __shared__ __attribute__((aligned(16))) double sUT[TB * C::S2];
@@ -1068,9 +1078,8 @@ int gpx_mfma_pair_trace(hipStream_t st, const double* Xa, long n, const double* 
 bool gpx_mfma_sym_trace_supported(int d) { return d >= 1 && kk_of(d) <= 8; }
 int gpx_mfma_sym_trace_grid(long n, int d) {
     (void)d;
-    const long nblk = (n + 127) / 128, gr = SYM_CT * 64 / 128;
-    const long a = nblk / gr, b = nblk % gr;
-    const long units = gr * a * (a + 1) / 2 + b * (a + 1);
+    const long nblk = (n + 127) / 128;
+    const long units = sym_units(nblk, sym_gr(nblk));
     return (int)(units < 1024 ? units : 1024);   // 2 resident workgroups per CU x 2 rounds of units in flight
 }
 // Xa, Ua, UaT from gpx_mfma_prepare(st, Xt, ldx, n, Xt, ldx, n, ...); M1 valid in its lower triangle; w = M1 + u v^T;
@@ -1086,16 +1095,16 @@ int gpx_mfma_sym_trace(hipStream_t st, const double* Xa, const double* Ua, const
     g.M1 = M1; g.ldm1 = ldm1;
     g.u = u; g.v = v;
     g.spart = spart;
-    const long nblk = (n + 127) / 128, gr = SYM_CT * 64 / 128;
-    const long a = nblk / gr, b = nblk % gr;
-    const long units = gr * a * (a + 1) / 2 + b * (a + 1);
+    const long nblk = (n + 127) / 128;
+    const int gr = sym_gr(nblk);
+    const long units = sym_units(nblk, gr);
     if (units > 0x3fffffffL) return GPX_ERR_ARG;
     const int grid = gpx_mfma_sym_trace_grid(n, d), n2 = gpx_mfma_n2(d);
     const long slot = gpx_pair_prof_open(st, 1, 4.0 * (double)n * (double)n);
     switch (kk_of(d)) {
-#define GPX_SYM_CASE(K) case K: hipLaunchKernelGGL((trace_sym_mfma_kernel<K, 2>), dim3(grid), dim3(256), 0, st, g, (int)units); break;
+#define GPX_SYM_CASE(K) case K: hipLaunchKernelGGL((trace_sym_mfma_kernel<K, 2>), dim3(grid), dim3(256), 0, st, g, (int)units, gr); break;
         GPX_SYM_CASE(1) GPX_SYM_CASE(2) GPX_SYM_CASE(3) GPX_SYM_CASE(4) GPX_SYM_CASE(5) GPX_SYM_CASE(6) GPX_SYM_CASE(7)
-        default: hipLaunchKernelGGL((trace_sym_mfma_kernel<8, 2>), dim3(grid), dim3(256), 0, st, g, (int)units); break;
+        default: hipLaunchKernelGGL((trace_sym_mfma_kernel<8, 2>), dim3(grid), dim3(256), 0, st, g, (int)units, gr); break;
 #undef GPX_SYM_CASE
     }
     hipLaunchKernelGGL(trace_sym_finish_kernel, dim3(d + 2), dim3(256), 0, st, spart, grid, n2, d, out);
