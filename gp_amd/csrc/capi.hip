@@ -72,7 +72,7 @@ int gpx_ctx_destroy(gpx_ctx* c) {
     DeviceGuard dg(c->dev);
     if (c->st) (void)hipStreamSynchronize(c->st);
     if (c->st2) (void)hipStreamSynchronize(c->st2);
-    DevBuf* bufs[] = {&c->X, &c->y, &c->U, &c->Xt, &c->Ut, &c->A, &c->W, &c->T, &c->Wd, &c->r, &c->alpha,
+    DevBuf* bufs[] = {&c->Tc, &c->X, &c->y, &c->U, &c->Xt, &c->Ut, &c->A, &c->W, &c->T, &c->Wd, &c->r, &c->alpha,
                       &c->nalpha, &c->scal, &c->trace_ws, &c->Kxu, &c->V, &c->Bm, &c->Cm, &c->Kuu, &c->Lu,
                       &c->Am, &c->LA, &c->Winv_u, &c->Winv_A, &c->Kuu_inv, &c->A_inv, &c->Wuu,
                       &c->Wd_u, &c->Wd_A, &c->red, &c->pred_K, &c->pred_xs, &c->pred_xst, &c->pred_out,

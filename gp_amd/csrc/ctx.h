@@ -41,6 +41,7 @@ struct gpx_ctx {
     DevBuf Xt, Ut;  // scaled, dimension-major [dpad][ld]
     long ldx = 0, ldu = 0;
     // dense workspaces
+    DevBuf Tc;           // scratch of the Lu chain of VFE while c->T holds split-K slabs (sparse.hip)
     DevBuf A, W, T, Wd;  // exact: n x n factor / inverse, trtri scratch, base-block inverses
     long lda = 0;
     DevBuf r, alpha, nalpha;

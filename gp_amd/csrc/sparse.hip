@@ -344,7 +344,11 @@ struct Sparse {
     // inputs, Kuu (+jitter on its diagonal) factored into Lu, Kxu
     // overlap: the Lu factor+inverse chain (one workgroup wide for most of its length) runs on the
     // side stream while the main stream builds Kxu.
-    int kernels(double kuu_jitter, bool fused_inverse = false, bool overlap = false) {
+    // defer_join (VFE): nothing of phase 1 needs Lu, so the main stream does NOT wait for the chain: it runs beside the
+    // HBM-bound GEMV F = Kux r (whose workgroups hold no LDS; the Kxu build's do, and the 150 KB base block of the chain
+    // found no CU until the 25 ms build had ended: profiles/r02d_vfe) and phase 2 follows it on the side stream anyway.
+    // The chain then takes its own scratch (c->Tc): c->T holds the split-K slabs of the Gram product meanwhile.
+    int kernels(double kuu_jitter, bool fused_inverse = false, bool overlap = false, bool defer_join = false) {
         int rc;
         if ((rc = gpx_scale_inputs(st, c->X.p, n, d, c->dpad, h.sc, c->Xt.p, c->ldx))) return rc;
         if ((rc = gpx_scale_inputs(st, c->U.p, m, d, c->dpad, h.sc, c->Ut.p, c->ldu))) return rc;
@@ -363,10 +367,17 @@ struct Sparse {
                 if ((rc = gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p))) return rc;
             }
             HIP_TRY(hipMemsetAsync(c->Winv_u.p, 0, (size_t)ldm * m * sizeof(double), sf));
-            if ((rc = gpx_potrf_inv(sf, m, c->Lu.p, ldm, c->Winv_u.p, ldm, c->T.p, c->info))) return rc;
+            double* tscr = c->T.p;
+            if (overlap && defer_join) {
+                if ((rc = c->Tc.ensure(gpx_trtri_scratch(m)))) return rc;
+                tscr = c->Tc.p;
+            }
+            if ((rc = gpx_potrf_inv(sf, m, c->Lu.p, ldm, c->Winv_u.p, ldm, tscr, c->info))) return rc;
             if (overlap) {
-                HIP_TRY(hipEventRecord(c->ev[1], sf));
-                HIP_TRY(hipStreamWaitEvent(st, c->ev[1], 0));
+                if (!defer_join) {
+                    HIP_TRY(hipEventRecord(c->ev[1], sf));
+                    HIP_TRY(hipStreamWaitEvent(st, c->ev[1], 0));
+                }
                 return GPX_OK;
             }
         } else if ((rc = gpx_potrf(st, m, c->Lu.p, ldm, c->Wd_u.p, c->info))) {
@@ -431,7 +442,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     const bool wh = fitc && c->fitc_whiten;
     const double* gram_op = wh ? c->V.p : c->Kxu.p;
     // ---- phase 1 ------------------------------------------------------------------------------
-    if ((rc = s.kernels(jitter, true, true))) return rc;  // Lu diag + Winv_u = Lu^-1
+    if ((rc = s.kernels(jitter, true, true, !fitc))) return rc;  // Lu diag + Winv_u = Lu^-1
     HIP_TRY(hipMemsetAsync(redT, 0, 16 * sizeof(double), st));
     if (mp > m) HIP_TRY(hipMemsetAsync(redF + m, 0, (mp - m) * sizeof(double), st));   // the padding travels with all-reduce #1
     if (fitc) {
