@@ -221,6 +221,47 @@ int gpx_cov_k(int cov, int64_t d, const double* hyp, const double* x1, int64_t p
     return rc;
 }
 
+int gpx_cov_dk_dhyp(int cov, int64_t d, const double* hyp, int64_t idx, const double* x1, int64_t p, const double* x2,
+                    int64_t q, const double* K, double* dK) {
+    if (!hyp || !x1 || !x2 || !dK || p <= 0 || q <= 0 || d <= 0 || idx < 0) return GPX_ERR_ARG;
+    if (d > GPX_MAX_DIM) return GPX_ERR_UNSUPPORTED;
+    const int nk = cov == GPX_COV_SE_ARD ? (int)d + 1 : 2;
+    if (idx >= nk) return GPX_ERR_ARG;   // "Wrong index for dk_dhyp" (CovSEiso.cpp:24-26)
+    std::vector<double> h(hyp, hyp + nk);
+    h.push_back(0.0);
+    h.push_back(0.0);
+    HypView hv;
+    int rc = parse_hyp(cov, (int)d, h.data(), hv);
+    if (rc) return rc;
+    const int dpad = (int)((d + 7) / 8 * 8);
+    const long l1 = gpx_ld(p), l2 = gpx_ld(q);
+    const int mode = idx == nk - 1 ? 2 : (cov == GPX_COV_SE_ARD ? 0 : 1);
+    DevBuf X1, X2, T1, T2, Kd, Od;
+    rc = X1.ensure(p * d);
+    if (!rc) rc = X2.ensure(q * d);
+    if (!rc) rc = T1.ensure(dpad * l1);
+    if (!rc) rc = T2.ensure(dpad * l2);
+    if (!rc) rc = Kd.ensure(p * q);
+    if (!rc) rc = Od.ensure(p * q);
+    if (!rc) {
+        rc = GPX_ERR_HIP;
+        if (hipMemcpy(X1.p, x1, (size_t)p * d * 8, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(X2.p, x2, (size_t)q * d * 8, hipMemcpyHostToDevice) == hipSuccess &&
+            (!K || hipMemcpy(Kd.p, K, (size_t)p * q * 8, hipMemcpyHostToDevice) == hipSuccess)) {
+            rc = gpx_scale_inputs(0, X1.p, p, (int)d, dpad, hv.sc, T1.p, l1);
+            if (!rc) rc = gpx_scale_inputs(0, X2.p, q, (int)d, dpad, hv.sc, T2.p, l2);
+            if (!rc && !K) rc = gpx_cov_build(0, T1.p, l1, p, T2.p, l2, q, dpad, hv.sf2, Kd.p, p, 0, 0.0);   // the 4-argument overload (CovSEard.cpp:23-27)
+            for (long q0 = 0; !rc && q0 < q; q0 += 32768) {   // grid.y limit
+                const long qc = q - q0 < 32768 ? q - q0 : 32768;
+                rc = gpx_dk_dhyp(0, p, qc, mode, (int)idx, (int)d, T1.p, l1, T2.p + q0, l2, Kd.p + q0 * p, p, Od.p + q0 * p, p);
+            }
+            if (!rc && hipMemcpy(dK, Od.p, (size_t)p * q * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = GPX_ERR_HIP;
+        }
+    }
+    X1.release(); X2.release(); T1.release(); T2.release(); Kd.release(); Od.release();
+    return rc;
+}
+
 // ---- MatrixSolverLLT with the factor kept on the device between decomp() and solve() / inverse() ----
 // The handle belongs to ONE device (the `device` argument of gpx_chol_factor; -1 = the caller's current one); every
 // entry point switches to it and restores the caller's current device on every exit path.  The solve / inverse

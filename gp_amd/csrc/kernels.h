@@ -24,6 +24,9 @@ int gpx_scale_inputs(hipStream_t st, const double* X, long n, int d, int dpad, c
                      double* Xt, long ldx);
 int gpx_cov_build(hipStream_t st, const double* Xt1, long ld1, long p, const double* Xt2, long ld2, long q,
                   int dpad, double sf2, double* out, long ldo, int lower, double diag_add);
+// one materialised dK (Cov::dk_dhyp): mode 0 K o ((x1_dim - x2_dim)/l)^2, 1 K o r2 (iso), 2: 2 K; scaled inputs as for cov_build
+int gpx_dk_dhyp(hipStream_t st, long p, long q, int mode, int dim, int d, const double* Xt1, long ld1, const double* Xt2, long ld2,
+                const double* K, long ldk, double* out, long ldo);
 // out[0..d-1] = S_i, out[d] = sum w K, out[d+1] = tr(w); partial_ws >= 2048*66 doubles
 int gpx_pair_trace(hipStream_t st, TraceArgs g, int d, double* partial_ws, long ws_doubles, double* out);
 #define GPX_TRACE_WS (2048L * 66)

@@ -347,6 +347,32 @@ __global__ void trace_finish_kernel(const double* __restrict__ partial, int nwg,
     }
 }
 
+
+// Cov::dk_dhyp (Cov/Cov.h:15-16; CovSEard.cpp:12-22, CovSEiso.cpp:12-31): ONE materialised dK from a K that is already
+// there, for callers of seam (1) (the training path never forms it).  mode 0: K o ((x1_i - x2_i) / l_i)^2 for dimension
+// dim (ARD, idx < d); mode 1: K o r2 with r2 over all dimensions (iso, idx = 0); mode 2: 2 K (the sf hyper).
+__global__ __launch_bounds__(256) void dk_dhyp_kernel(long p, long q, int mode, int dim, int d, const double* __restrict__ Xt1,
+                                                      long ld1, const double* __restrict__ Xt2, long ld2,
+                                                      const double* __restrict__ K, long ldk, double* __restrict__ out, long ldo) {
+    const long a = (long)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (a >= p || b >= q) return;
+    const double k = K[a + b * ldk];
+    double v;
+    if (mode == 2) {
+        v = 2 * k;
+    } else if (mode == 0) {
+        const double t = Xt1[(long)dim * ld1 + a] - Xt2[(long)dim * ld2 + b];
+        v = k * (t * t);
+    } else {
+        double r2 = 0.0;
+        for (int i = 0; i < d; ++i) {
+            const double t = Xt1[(long)i * ld1 + a] - Xt2[(long)i * ld2 + b];
+            r2 += t * t;   // CovSEiso.cpp:17-19 sums the squares in this order
+        }
+        v = k * r2;
+    }
+    out[a + b * ldo] = v;
+}
 }  // namespace
 
 int gpx_scale_inputs(hipStream_t st, const double* X, long n, int d, int dpad, const ScaleArgs& sc,
@@ -456,5 +482,15 @@ int gpx_pair_prof_end(int cls, double* total_ms, double* total_bytes, long* laun
     *total_ms = ms;
     *total_bytes = by;
     *launches = cnt;
+    return GPX_OK;
+}
+
+int gpx_dk_dhyp(hipStream_t st, long p, long q, int mode, int dim, int d, const double* Xt1, long ld1, const double* Xt2, long ld2,
+                const double* K, long ldk, double* out, long ldo) {
+    if (p <= 0 || q <= 0) return GPX_OK;
+    if (q > 65535) return GPX_ERR_ARG;
+    hipLaunchKernelGGL(dk_dhyp_kernel, dim3((unsigned)((p + 255) / 256), (unsigned)q), dim3(256), 0, st, p, q, mode, dim, d, Xt1, ld1,
+                       Xt2, ld2, K, ldk, out, ldo);
+    HIP_TRY(hipGetLastError());
     return GPX_OK;
 }

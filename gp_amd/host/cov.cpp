@@ -26,6 +26,15 @@ MatrixXd Cov::k(const VectorXd& hyp, const MatrixXd& x1, const MatrixXd& x2) con
     if (rc) throw std::runtime_error("gpx_cov_k failed with status " + std::to_string(rc));
     return K;
 }
+MatrixXd Cov::dk_dhyp_device(const VectorXd& hyp, std::size_t idx, const MatrixXd& x1, const MatrixXd& x2, const MatrixXd& K) const {
+    if (x1.rows() != _dim || x2.rows() != _dim || K.rows() != x1.cols() || K.cols() != x2.cols())
+        throw std::invalid_argument("Cov::dk_dhyp: shapes");
+    MatrixXd dK(K.rows(), K.cols());
+    const int rc = gpx_cov_dk_dhyp(abi_id(), (int64_t)_dim, hyp.data(), (int64_t)idx, x1.data(), (int64_t)x1.cols(), x2.data(),
+                                   (int64_t)x2.cols(), K.data(), dK.data());
+    if (rc) throw std::runtime_error("gpx: cov_dk_dhyp failed with status " + std::to_string(rc));
+    return dK;
+}
 MatrixXd Cov::dk_dhyp(const VectorXd& hyp, std::size_t idx, const MatrixXd& x1, const MatrixXd& x2) const {
     return dk_dhyp(hyp, idx, x1, x2, k(hyp, x1, x2));
 }
@@ -81,18 +90,7 @@ int CovSEard::abi_id() const { return GPX_COV_SE_ARD; }
 double CovSEard::inv_lscale2(const VectorXd& hyp, std::size_t k) const { return std::exp(-2 * hyp[k]); }
 MatrixXd CovSEard::dk_dhyp(const VectorXd& hyp, std::size_t idx, const MatrixXd& x1, const MatrixXd& x2,
                            const MatrixXd& K) const {
-    MatrixXd dK(K.rows(), K.cols());
-    if (idx < _dim) {
-        const double li = std::exp(-1 * hyp[idx]);
-        for (std::size_t b = 0; b < K.cols(); ++b)
-            for (std::size_t a = 0; a < K.rows(); ++a) {
-                const double t = li * x1(idx, a) - li * x2(idx, b);
-                dK(a, b) = K(a, b) * (t * t);
-            }
-    } else {
-        for (std::size_t e = 0; e < K.size(); ++e) dK.data()[e] = 2 * K.data()[e];
-    }
-    return dK;
+    return dk_dhyp_device(hyp, idx, x1, x2, K);   // CovSEard.cpp:12-22 on the device
 }
 std::pair<VectorXd, VectorXd> CovSEard::cov_hyp_range(const MatrixXd& xs, const VectorXd& ys) const {
     VectorXd lb(num_hyp()), ub(num_hyp());
@@ -120,25 +118,11 @@ int CovSEiso::abi_id() const { return GPX_COV_SE_ISO; }
 double CovSEiso::inv_lscale2(const VectorXd& hyp, std::size_t) const { return std::exp(-2 * hyp[0]); }
 MatrixXd CovSEiso::dk_dhyp(const VectorXd& hyp, std::size_t idx, const MatrixXd& x1, const MatrixXd& x2,
                            const MatrixXd& K) const {
-    MatrixXd dK(K.rows(), K.cols());
-    if (idx == 0) {
-        const double l = std::exp(hyp[0]);
-        for (std::size_t b = 0; b < K.cols(); ++b)
-            for (std::size_t a = 0; a < K.rows(); ++a) {
-                double r2 = 0;
-                for (std::size_t i = 0; i < _dim; ++i) {
-                    const double t = x1(i, a) / l - x2(i, b) / l;
-                    r2 += t * t;
-                }
-                dK(a, b) = K(a, b) * r2;
-            }
-    } else if (idx == 1) {
-        for (std::size_t e = 0; e < K.size(); ++e) dK.data()[e] = 2 * K.data()[e];
-    } else {
+    if (idx > 1) {
         std::fprintf(stderr, "Wrong index for dk_dhyp\n");  // CovSEiso.cpp:24-26
         std::exit(EXIT_FAILURE);
     }
-    return dK;
+    return dk_dhyp_device(hyp, idx, x1, x2, K);   // CovSEiso.cpp:12-23 on the device
 }
 std::pair<VectorXd, VectorXd> CovSEiso::cov_hyp_range(const MatrixXd& xs, const VectorXd& ys) const {
     VectorXd lb(2, -std::numeric_limits<double>::infinity()), ub(2, 0.5 * std::log(0.5 * DBL_MAX));

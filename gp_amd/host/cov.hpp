@@ -2,9 +2,9 @@
 //
 // Same class names and method meanings as the reference.  k() runs the HIP kernel-matrix build
 // (gpx_cov_k); the O(1)/O(n) members (num_hyp, default_hyp, cov_hyp_range, diag_k, diag_dk_dhyp)
-// are host code.  dk_dhyp materialises one dK on the host from a K that is already there — it
-// exists for API compatibility only: the training path never calls it (the fused trace kernel
-// contracts all dK at once on the device).
+// are host code.  dk_dhyp materialises one dK ON THE DEVICE (gpx_cov_dk_dhyp) from a K that is already there
+// — it exists for API compatibility only: the training path never calls it (the fused trace kernel
+// contracts all dK at once).
 #pragma once
 #include <utility>
 #include "dense.hpp"
@@ -38,6 +38,8 @@ public:
     virtual MatrixXd diag_dk_dx1(const VectorXd& hyp, const VectorXd& x1, const RowVectorXd& K) const;
 
 protected:
+    // one dK on the device (gpx_cov_dk_dhyp): host matrices in, host matrix out, as seam (1) demands
+    MatrixXd dk_dhyp_device(const VectorXd& hyp, std::size_t idx, const MatrixXd& x1, const MatrixXd& x2, const MatrixXd& K) const;
     virtual std::size_t sf_index() const = 0;
     virtual double inv_lscale2(const VectorXd& hyp, std::size_t k) const = 0;
     // [lower, upper] of log lengthscale for input dimension i (CovSEard.cpp:46-66)

@@ -301,6 +301,21 @@ def cov_k(cov, hyp, x1, x2):
     return K.T
 
 
+lib.gpx_cov_dk_dhyp.argtypes = [_i, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]
+
+
+def cov_dk_dhyp(cov, hyp, idx, x1, x2, K=None):
+    """d k(x1, x2) / d hyp[idx] (p, q); K (p, q) as returned by cov_k, or None (computed first)."""
+    x1, x2, hyp = _c(x1), _c(x2), _c(hyp)
+    p, d = x1.shape
+    q = x2.shape[0]
+    Kc = None if K is None else np.ascontiguousarray(np.asarray(K, dtype=np.float64).T)   # column-major p x q
+    dK = np.empty((q, p))
+    check(lib.gpx_cov_dk_dhyp(cov, d, hyp.ctypes.data, idx, x1.ctypes.data, p, x2.ctypes.data, q,
+                              Kc.ctypes.data if Kc is not None else None, dK.ctypes.data), "cov_dk_dhyp")
+    return dK.T
+
+
 def chol_solve(A, B=None, want_inverse=False):
     """Returns (spd, logdet, X, Inv) for symmetric A (lower triangle read)."""
     A = np.asarray(A, dtype=np.float64)

@@ -166,6 +166,12 @@ int gpx_predict_with_grad(gpx_ctx* ctx, const double* Xs, int64_t t, double* mu,
  * K p x q column-major.  hyp holds at least the kernel hypers. */
 int gpx_cov_k(int cov, int64_t d, const double* hyp, const double* x1, int64_t p, const double* x2,
               int64_t q, double* K);
+/* Cov::dk_dhyp (Cov/Cov.h:15-16; CovSEard.cpp:12-27, CovSEiso.cpp:12-31) on HOST buffers: dK (p x q column-major) =
+ * d k(x1, x2) / d hyp[idx] from K = k(x1, x2) (p x q; NULL: the 4-argument overload, K is computed first).  idx < d: one
+ * lengthscale (ARD) / idx 0: the shared one (iso); the last kernel hyper (sf): 2 K.  For API compatibility with seam (1):
+ * the training path never materialises a dK (gpx_nll_grad contracts all of them in one fused pass). */
+int gpx_cov_dk_dhyp(int cov, int64_t d, const double* hyp, int64_t idx, const double* x1, int64_t p, const double* x2,
+                    int64_t q, const double* K, double* dK);
 /* MatrixSolverLLT (MatrixSolver.cpp:6-29) on HOST buffers: A n x n column-major (lower read).
  * *spd = check_SPD(); logdet, X = solve(B) (n x nrhs, in place) and Inv = inverse() are optional. */
 int gpx_chol_solve(int64_t n, const double* A, int* spd, double* logdet, double* B, int64_t nrhs,

@@ -118,6 +118,9 @@ int main(int argc, char** argv) {
         const MatrixXd K = cov.k(h, X.leftCols(5), X.leftCols(7));
         VectorXd flat(std::vector<double>(K.data(), K.data() + K.size()));
         pv("iso_k", flat);
+        const MatrixXd dKi = cov.dk_dhyp(h, 0, X.leftCols(5), X.leftCols(7));   // Cov/Cov.h:15, on the device
+        VectorXd dflat(std::vector<double>(dKi.data(), dKi.data() + dKi.size()));
+        pv("iso_dk0", dflat);
         CovSEard ard(X.rows());
         VectorXd ha(X.rows() + 1, 0.5);
         MatrixXd Kxx = ard.k(ha, X.leftCols(40), X.leftCols(40));

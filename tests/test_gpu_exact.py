@@ -201,3 +201,22 @@ def test_setk_residual_spd_check_escalates_like_the_literal_check(gpx, n, d, ls,
         # cond(K + sn2 I) ~ 1e13 at the accepted noise: two fp64 solves agree to a few digits only (measured 1e-3)
         assert np.all(np.isfinite(mu)) and np.max(np.abs(mu - mu_o)) <= 2e-2 * np.max(np.abs(mu_o))
     ctx.close()
+
+
+@pytest.mark.parametrize("cov", [0, 1])
+def test_cov_dk_dhyp_on_the_device_matches_the_oracle(gpx, cov):
+    """Cov::dk_dhyp (Cov/Cov.h:15-16; CovSEard.cpp:12-27, CovSEiso.cpp:12-31) through gpx_cov_dk_dhyp: every kernel
+    hyper, with the caller's K (5-argument overload) and without (4-argument overload: K computed first)."""
+    rng = np.random.default_rng(4)
+    d, p, q = 7, 131, 67
+    x1, x2 = rng.normal(size=(p, d)), rng.normal(size=(q, d))
+    hyp = np.concatenate([0.3 * rng.normal(size=d) + 0.5, [0.2]]) if cov == 0 else np.array([0.7, 0.2])
+    K = oracle.cov_k(cov, hyp, x1, x2)
+    for idx in range(len(hyp)):
+        want = oracle.cov_dk_dhyp(cov, hyp, idx, x1, x2, K)
+        got = gpx.cov_dk_dhyp(cov, hyp, idx, x1, x2, K)
+        got4 = gpx.cov_dk_dhyp(cov, hyp, idx, x1, x2)
+        assert rel(got, want) <= 1e-15, (cov, idx)
+        assert rel(got4, want) <= 1e-14, (cov, idx)
+    assert gpx.lib.gpx_cov_dk_dhyp(cov, d, hyp.ctypes.data, len(hyp), x1.ctypes.data, p, x2.ctypes.data, q, None,
+                                   np.empty((q, p)).ctypes.data) == 1     # "Wrong index for dk_dhyp"

@@ -82,6 +82,8 @@ def test_facade_fixed_hypers_match_oracle(workdir):
     assert list(r["vfe_failure_fallback"]) == [1, 1] and r["fitc_failure_keeps_point"][0] == 1
     Kiso = oracle.cov_k(1, np.array([0.3, 0.1]), X[:5], X[:7])
     assert rel(r["iso_k"], Kiso.T.ravel()) < 1e-14               # column-major 5 x 7
+    dK0 = oracle.cov_dk_dhyp(1, np.array([0.3, 0.1]), 0, X[:5], X[:7], Kiso)
+    assert rel(r["iso_dk0"], dK0.T.ravel()) < 1e-14             # Cov::dk_dhyp through the facade (device path)
     assert r["llt_spd"][0] == 1 and r["llt_inv_err"][0] < 1e-9
 
 
