@@ -1,5 +1,5 @@
 """The JSON line of bench.py, as committed beside the rocprofv3 summary of the same command
-(profiles/r02d_default/bench.json), carries every field of the driver's contract plus the `roofline` and
+(profiles/r03_default/bench.json), carries every field of the driver's contract plus the `roofline` and
 `cpu_baseline` objects, and its numbers are consistent with one another."""
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r02d_default", "bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r03_default", "bench.json")) as f:
         lines = [l for l in f.read().splitlines() if l.strip()]
     assert len(lines) == 1            # stdout carries exactly one line
     return json.loads(lines[0])
@@ -44,6 +44,18 @@ def test_roofline_and_cpu_baseline_objects():
     for h in d["hbm_rooflines"] + d["fitc"]["hbm_rooflines"]:   # the HBM-bound kernels, live HIP-event timing
         assert h["bound"] == "hbm" and h["peak"] == 8000.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12 and 0 < h["frac"] < 1
     assert d["exact8192"]["config"]["n"] == 8192 and d["exact8192"]["ms_per_step"] > 0
+    # round 3: every BASELINE config in the one line — VFE n = 2^22 (configs[4]) and config0 (the reference's own data)
+    v = d["vfe"]
+    assert v["config"]["n"] == 1 << 22 and v["config"]["m"] == 2048 and v["config"]["d"] == 50 and v["ms_per_step"] > 0
+    for h in v["hbm_rooflines"]:
+        assert h["bound"] == "hbm" and 0 < h["frac"] < 1
+    c0 = d["config0"]
+    assert set(c0["sizes"]) == {"500", "2000", "8000"} and c0["mle_gp_8000"]["returncode"] == 0 and c0["mle_gp_8000"]["evaluations"] > 0
+    for n, e in c0["sizes"].items():
+        assert e["gpu_nll_grad_ms"] > 0 and e["gpu_setK_ms"] > 0 and e["gpu_predict_2000_ms"] > 0
+        if n != "8000":
+            assert e["nll_rel_err_vs_cpu_port"] <= 1e-9 and e["mu_rel_err_vs_cpu_port"] <= 1e-9 and e["cpu_port_nll_grad_s_1_thread"] > 0
+    assert any(h["traffic"] for h in d["hbm_rooflines"])     # HBM-side bytes from the committed --pmc passes
 
 
 def test_bench_gpus_n_starts_n_distinct_ranks_before_any_gpu_call():
