@@ -16,7 +16,21 @@
 #include <cstring>
 #include <limits>
 
+#include <chrono>
+
 namespace {
+
+// GPX_TRACE=1: host-side stage markers of a sparse evaluation on stderr (ms since the call began): where the HOST waits
+struct StageTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    StageTrace() : on(getenv("GPX_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) const {
+        if (on)
+            fprintf(stderr, "gpx trace %9.3f ms  %s\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+    }
+};
 
 const double INF = std::numeric_limits<double>::infinity();
 constexpr int PW = 8;  // partial sums per block
@@ -403,11 +417,14 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
                         double* nll, double* grad) {
     if (c->n <= 0 || c->m <= 0) return GPX_ERR_STATE;
     if (c->prepared_model == GPX_MODEL_EXACT) c->prepared_model = -1;  // Xt is rescaled below
+    const StageTrace tr;
+    tr.mark(model == GPX_MODEL_FITC ? "FITC evaluation begins" : "VFE evaluation begins");
     Sparse s;
     s.c = c; s.st = c->st; s.n = c->n; s.m = c->m; s.d = c->d; s.model = model; s.cov = cov;
     int rc = parse_hyp(cov, c->d, hyp, s.h);
     if (rc) return rc;
     if ((rc = s.alloc(calc_grad != 0))) return rc;
+    tr.mark("workspaces allocated");
     const HypView& h = s.h;
     const long n = s.n, m = s.m, ldn = s.ldn, ldm = s.ldm, ldk = s.ldk;
     const GemmPanels pnK = s.pn_of(true, true, false, false);   // Gram products: both operands K-contiguous over the n rows
@@ -473,7 +490,9 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         const GemmPanels pn = s.pn_of(true, false, true, false);
         if ((rc = gpx_gemm(st, 0, 1, n, m, m, 1.0, c->V.p, ldk, c->Winv_u.p, ldm, 0.0, c->Bm.p, ldk, GEMM_KLO_N, &pn))) return rc;
     }
+    tr.mark("phase 1 enqueued");
     if ((rc = s.allreduce(redF, mp + m * m + 16, c->st2, c->ev[0]))) return rc;
+    tr.mark("all-reduce #1 returned to the host");
 
     // ---- phase 2 (side stream) ------------------------------------------------------------------
     // A = sn2*Kuu + S (FITC.cpp:217, VFE.cpp:174), factor, a = A^-1 F
@@ -511,7 +530,9 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     HIP_TRY(hipMemcpyAsync(hs, c->scal.p, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hs + 8, redT, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hs + 16, c->info, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    tr.mark("phase 2 enqueued");
     HIP_TRY(hipStreamSynchronize(st));  // the side stream is drained: phase 3 needs no event
+    tr.mark("phase 2 done on the device (side stream drained)");
     st = st_main;
     s.st = st;
     int info[2];
@@ -580,7 +601,9 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Bm.p, ldk, c->Bm.p, ldk, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
                                   wv, &pnK)))
             return rc;
+        tr.mark("phase 3 enqueued");
         if ((rc = s.allreduce(red, m * m + GPX_MAX_DIM + 32, st))) return rc;
+        tr.mark("all-reduce #2 returned to the host");
         hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, red, m);
         // W_uu = sn2 A^-1 - Kuu^-1 + a a^T + B^T diag(w) B / sn2
         hipLaunchKernelGGL(mm_combine_full_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, h.sn2, c->A_inv.p, ldm, -1.0,
@@ -607,7 +630,9 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         s.finish_partials(m * m, c->scal.p + S_TRAS, 1);
         if ((rc = gpx_gemm(st, 0, 0, m, m, m, 1.0, c->Kuu_inv.p, ldm, red, m, 0.0, c->Am.p, ldm, 0))) return rc;
         if ((rc = gpx_gemm(st, 0, 0, m, m, m, 1.0, c->Am.p, ldm, c->Kuu_inv.p, ldm, 0.0, c->LA.p, ldm, 0))) return rc;
+        tr.mark("phase 3 enqueued");
         if ((rc = s.allreduce(redT, GPX_MAX_DIM + 32, st))) return rc;
+        tr.mark("all-reduce #2 returned to the host");
         // W_uu = 0.5 [a a^T + sn2 A^-1 - Kuu^-1 + G/sn2]
         hipLaunchKernelGGL(mm_combine_full_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, 0.5 * h.sn2, c->A_inv.p, ldm, -0.5,
                            c->Kuu_inv.p, ldm, 0.5, a_vec, 0.5 / h.sn2, c->LA.p, ldm, c->Wuu.p, ldm);
@@ -624,7 +649,9 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     HIP_TRY(hipMemcpyAsync(hs + 32, tuu, (d + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hs + 32 + GPX_MAX_DIM + 8, redT, (GPX_MAX_DIM + 32) * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hs + 4, c->scal.p + S_TRAS, sizeof(double), hipMemcpyDeviceToHost, st));
+    tr.mark("phase 4 enqueued");
     HIP_TRY(hipStreamSynchronize(st));
+    tr.mark("evaluation done on the device");
     const double* Suu = hs + 32;                         // [d | sum W K | tr W]
     const double* Sxu = hs + 32 + GPX_MAX_DIM + 8;       // [d | sum W K | -]
     const double* tail = Sxu + GPX_MAX_DIM + 8;
