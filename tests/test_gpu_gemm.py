@@ -241,3 +241,39 @@ def test_gemm_32_tiles_for_products_of_few_tiles(layout):
     assert np.max(np.abs(C - D @ L.T)) <= 1e-11
     C = lib.dgemm(L, D.T.copy(), flags=lib.GEMM_KHI_M | lib.GEMM_HEAVY_LAST, b_kc=True)   # A(m,k) = L[m,k], zero for k > m
     assert np.max(np.abs(C - L @ D)) <= 1e-11
+
+
+@pytest.mark.parametrize("n,m,scale", [(50000, 200, False), (40000, 384, True), (300, 96, False)])
+def test_splitk_gram_with_row_panelled_operands(n, m, scale):
+    """S = Kux [G] Kxu with the n x m operand in ROW PANELS (GemmPanels: element (a, b) at (a / pan) pst + a % pan + b pan,
+    one split-K slab per panel) against NumPy, and against the plain column-major call on the same numbers."""
+    import ctypes as C
+    gpx = _lib()
+    L = gpx.lib
+    _vp, _i64, _i, _d = C.c_void_p, C.c_int64, C.c_int, C.c_double
+    L.gpx_dgemm_splitk_panelled.argtypes = [_i64, _i64, _i64, _d, _vp, _vp, _i64, _i64, _d, _vp, _i64, _i, _vp, _i64, _vp]
+    L.gpx_dgemm_splitk_panel_rows.argtypes = [_i64, _i64, _i64, _i, _i64]
+    L.gpx_dgemm_splitk_panel_rows.restype = _i64
+    work = 64 * m * m
+    pan = L.gpx_dgemm_splitk_panel_rows(m, m, n, gpx.GEMM_LOWER, work)
+    assert pan % 128 == 0 and pan > 0
+    npan = (n + pan - 1) // pan
+    pst = pan * m
+    rng = np.random.default_rng(n)
+    K = rng.normal(size=(m, n))
+    g = rng.uniform(0.5, 1.5, size=n)
+    P = np.full((npan, m, pan), np.nan)                      # rows of the last panel beyond n are never read
+    for p in range(npan):
+        r0, r1 = p * pan, min(n, (p + 1) * pan)
+        P[p, :, :r1 - r0] = K[:, r0:r1]
+    dP, dg = gpx.DeviceBuffer.from_numpy(P), gpx.DeviceBuffer.from_numpy(g)
+    w, c = gpx.DeviceBuffer(work), gpx.DeviceBuffer(m * m)
+    c.zero()
+    gpx.check(L.gpx_dgemm_splitk_panelled(m, m, n, 1.0, dP.ptr, dP.ptr, pan, pst, 0.0, c.ptr, m, gpx.GEMM_LOWER, w.ptr, work,
+                                          dg.ptr if scale else None), "panelled")
+    got = c.to_numpy().reshape(m, m).T
+    want = (K * g) @ K.T if scale else K @ K.T
+    low = np.tril(np.ones((m, m), bool))
+    assert np.max(np.abs(got - want)[low]) <= 1e-12 * np.max(np.abs(want))
+    plain = gpx.dgemm(K, K, a_kc=True, b_kc=True, flags=gpx.GEMM_LOWER, splitk_work=work, kscale=g if scale else None)
+    assert np.max(np.abs(got - plain)[low]) <= 1e-12 * np.max(np.abs(want))
