@@ -162,6 +162,25 @@ int spd_residual(gpx_ctx* c, const HypView& h, int cols, double* inv_err) {
     return GPX_OK;
 }
 
+// K + sn2 I -> c->A (lower triangle) from the scaled inputs in c->Xt (GP.cpp:128-129).  On the matrix cores where the
+// dimension allows it (d <= 62; leaves the centred, augmented operands in c->Xa / Ua / UaT for the gradient trace), else by
+// direct differences on the vector units; the diagonal is sf2 + sn2 exactly either way.
+int build_K(gpx_ctx* c, const HypView& h) {
+    const long n = c->n;
+    const int d = c->d;
+    int rc;
+    if (c->mfma_pairwise && gpx_mfma_pair_supported(d)) {
+        const long ldxa = gpx_mfma_ldxa(n), ldua = gpx_mfma_ldua(n);
+        const int dk = gpx_mfma_dk(d), n2 = gpx_mfma_n2(d);
+        if ((rc = c->Xa.ensure(dk * ldxa)) || (rc = c->Ua.ensure(dk * ldua)) || (rc = c->UaT.ensure(ldua * n2)) ||
+            (rc = c->cen.ensure(GPX_MAX_DIM)))
+            return rc;
+        if ((rc = gpx_mfma_prepare(c->st, c->Xt.p, c->ldx, n, c->Xt.p, c->ldx, n, d, c->cen.p, c->Xa.p, c->Ua.p, c->UaT.p))) return rc;
+        return gpx_mfma_cov_sym_build(c->st, c->Xa.p, c->Ua.p, n, d, h.sf2, h.sn2, c->A.p, c->lda);
+    }
+    return gpx_cov_build(c->st, c->Xt.p, c->ldx, n, c->Xt.p, c->ldx, n, c->dpad, h.sf2, c->A.p, c->lda, 1, h.sn2);
+}
+
 // K + sn2 I -> A (lower), factor in place, alpha = (K + sn2 I)^-1 (y - mean).  Leaves the device
 // scalars scal[0] = sum log L_ii, scal[1..3] = {r.alpha, sum r, sum alpha}.
 int factor_and_solve(gpx_ctx* c, int cov, const double* hyp, HypView& h) {
@@ -175,8 +194,7 @@ int factor_and_solve(gpx_ctx* c, int cov, const double* hyp, HypView& h) {
     if ((rc = gpx_scale_inputs(c->st, c->X.p, n, c->d, c->dpad, h.sc, c->Xt.p, c->ldx))) return rc;
     HIP_TRY(hipMemsetAsync(c->info, 0, sizeof(int), c->st));
     // GP.cpp:128-129: K = k(X, X); decomp(K + sn2 * I)
-    if ((rc = gpx_cov_build(c->st, c->Xt.p, c->ldx, n, c->Xt.p, c->ldx, n, c->dpad, h.sf2, c->A.p, c->lda, 1, h.sn2)))
-        return rc;
+    if ((rc = build_K(c, h))) return rc;
     if ((rc = gpx_potrf(c->st, n, c->A.p, c->lda, c->Wd.p, c->info))) return rc;
     // GP.cpp:138-141
     if ((rc = gpx_vec_shift(c->st, n, c->y.p, h.mean, 1.0, c->r.p))) return rc;
@@ -239,8 +257,7 @@ int gpx_exact_nll_grad(gpx_ctx* c, int cov, const double* hyp, int calc_grad, do
             c->w_clean_n = n;
             c->w_clean_lda = c->lda;
         }
-        if ((rc = gpx_cov_build(c->st, c->Xt.p, c->ldx, n, c->Xt.p, c->ldx, n, c->dpad, h.sf2, c->A.p, c->lda, 1, h.sn2)))
-            return rc;
+        if ((rc = build_K(c, h))) return rc;
         if ((rc = gpx_potrf_inv(c->st, n, c->A.p, c->lda, c->W.p, c->lda, c->T.p, c->info))) return rc;
         if ((rc = gpx_vec_shift(c->st, n, c->y.p, h.mean, 1.0, c->r.p))) return rc;
         if ((rc = gpx_gemv_n(c->st, n, n, 1.0, c->W.p, c->lda, c->r.p, 0.0, c->nalpha.p, 1))) return rc;
@@ -286,12 +303,9 @@ int gpx_exact_nll_grad(gpx_ctx* c, int cov, const double* hyp, int calc_grad, do
     if (c->mfma_pairwise && gpx_mfma_sym_trace_supported(d)) {
         // on the matrix cores: r2 from the norm expansion of the centred inputs, the per-dimension sums as a second
         // contraction (pairwise_mfma.hip); K itself keeps the direct differences (exact sf2 + sn2 diagonal)
-        const long ldxa = gpx_mfma_ldxa(n), ldua = gpx_mfma_ldua(n);
-        const int dk = gpx_mfma_dk(d), n2 = gpx_mfma_n2(d), grid = gpx_mfma_sym_trace_grid(n, d);
-        if ((rc = c->Xa.ensure(dk * ldxa)) || (rc = c->Ua.ensure(dk * ldua)) || (rc = c->UaT.ensure(ldua * n2)) ||
-            (rc = c->cen.ensure(GPX_MAX_DIM)) || (rc = c->spart.ensure((long)grid * (n2 + 2))))
-            return rc;
-        if ((rc = gpx_mfma_prepare(c->st, c->Xt.p, c->ldx, n, c->Xt.p, c->ldx, n, d, c->cen.p, c->Xa.p, c->Ua.p, c->UaT.p))) return rc;
+        // (the centred, augmented operands were left in c->Xa / Ua / UaT by build_K at these hypers)
+        const int n2 = gpx_mfma_n2(d), grid = gpx_mfma_sym_trace_grid(n, d);
+        if ((rc = c->spart.ensure((long)grid * (n2 + 2)))) return rc;
         if ((rc = gpx_mfma_sym_trace(c->st, c->Xa.p, c->Ua.p, c->UaT.p, n, d, h.sf2, c->A.p, c->lda, c->nalpha.p, c->alpha.p,
                                      c->spart.p, tout)))
             return rc;

@@ -53,6 +53,9 @@ int gpx_mfma_cov_build(hipStream_t st, const double* Xa, long n, const double* U
 int gpx_mfma_pair_trace(hipStream_t st, const double* Xa, long n, const double* Ua, const double* UaT, long m, int d, double sf2,
                         const TraceArgs& w, double* cpart, double* spart, double* cvec, double* out, long pan = 0, long pst = 0);
 
+// k(X, X) + diag_add I on and below the diagonal (whole diagonal tiles) on the matrix cores, exact sf2 + diag_add diagonal
+int gpx_mfma_cov_sym_build(hipStream_t st, const double* Xa, const double* Ua, long n, int d, double sf2, double diag_add,
+                           double* out, long ldo);
 // the exact GP's trace on the matrix cores: symmetric weights w = M1 + u v^T, M1 valid in its lower triangle, both point
 // sets = the training set (Ua / UaT prepared from the same points as Xa); d <= 30; spart: grid * (n2 + 2) doubles
 bool gpx_mfma_sym_trace_supported(int d);

@@ -842,6 +842,73 @@ __global__ void trace_sym_finish_kernel(const double* __restrict__ spart, int nw
     if (threadIdx.x == 0) out[i] = red[0];
 }
 
+
+// K + diag_add I on and below the diagonal for the exact GP (GP.cpp:128-129: k(X, X) + sn2 I), on the matrix cores:
+// r2 from the same contraction as cov_mfma_kernel with both point sets = the training set, work units over the triangle as
+// in trace_sym_mfma_kernel; the diagonal is sf2 + diag_add EXACTLY (r2_aa forced to 0, what the direct differences of
+// util.cpp:64-75 give), whole diagonal tiles are written (symmetric values above the diagonal inside them: nothing reads them).
+template <int KK>
+__global__ __launch_bounds__(256, 2) void cov_sym_mfma_kernel(const MfmaPairArgs g, int nunit, int GR, double diag_add) {
+    using C = Cfg<KK>;
+    constexpr int TB = C::TB, RB = 128;
+    const int CT = GR * RB / TB;
+    __shared__ __attribute__((aligned(16))) double sU[C::DK * C::S1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const bool vec = ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (g.ldo % 2 == 0);
+    for (int unit = blockIdx.x; unit < nunit; unit += gridDim.x) {
+        int a_ = 0;
+        while (GR * (a_ + 1) * (a_ + 2) / 2 <= unit) ++a_;
+        const int o_ = unit - GR * a_ * (a_ + 1) / 2;
+        const int blk = GR * a_ + o_ / (a_ + 1), ch = o_ % (a_ + 1);
+        const long row0 = (long)blk * RB;
+        const long a0 = row0 + 32 * wv + 2 * l15;   // this lane's two rows
+        const long bend = min((long)g.n, row0 + RB);
+        const long bfirst = (long)ch * CT * TB, blast = min(bend, bfirst + (long)CT * TB);
+        double xf[2][KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const v2d x = *reinterpret_cast<const v2d*>(g.Xa + (long)(4 * kk + l4) * g.ldxa + a0);
+            xf[0][kk] = x.x;
+            xf[1][kk] = x.y;
+        }
+        const bool rows_in = row0 + RB <= g.n;
+        for (long b0 = bfirst; b0 < blast; b0 += TB) {
+            __syncthreads();
+            stage_u<KK, false>(g, b0, sU, nullptr);
+            __syncthreads();
+            const bool below = b0 + TB <= row0;
+            const bool full = rows_in && vec && b0 + TB <= g.n;
+#pragma unroll
+            for (int bt = 0; bt < TB / 16; ++bt) {
+                v4d D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    const double ua = sU[(4 * kk + l4) * C::S1 + 16 * bt + l15];
+                    D0 = mfma(ua, xf[0][kk], D0);
+                    D1 = mfma(ua, xf[1][kk], D1);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long b = b0 + 16 * bt + 4 * r + l4;
+                    double k0 = g.sf2 * exp_nonpos(-0.5 * fmax(D0[r], 0.0));
+                    double k1 = g.sf2 * exp_nonpos(-0.5 * fmax(D1[r], 0.0));
+                    if (!below) {
+                        if (b == a0) k0 = g.sf2 + diag_add;
+                        if (b == a0 + 1) k1 = g.sf2 + diag_add;
+                    }
+                    double* o = g.out + a0 + b * g.ldo;
+                    if (full) {
+                        *reinterpret_cast<v2d*>(o) = (v2d){k0, k1};
+                    } else if (b < g.n) {
+                        if (a0 < g.n) o[0] = k0;
+                        if (a0 + 1 < g.n) o[1] = k1;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- operand preparation ----------------------------------------------------------------------------
 // cen[i] = mean over the m inducing points of the scaled coordinate i
 __global__ void centre_kernel(const double* __restrict__ Ut, long ldu, long m, double* __restrict__ cen) {
@@ -1108,6 +1175,36 @@ int gpx_mfma_sym_trace(hipStream_t st, const double* Xa, const double* Ua, const
 #undef GPX_SYM_CASE
     }
     hipLaunchKernelGGL(trace_sym_finish_kernel, dim3(d + 2), dim3(256), 0, st, spart, grid, n2, d, out);
+    gpx_pair_prof_close(st, slot);
+    HIP_TRY(hipGetLastError());
+    return GPX_OK;
+}
+
+// K + diag_add I, lower triangle (whole tiles on the diagonal), of the training set against itself: d <= 62
+int gpx_mfma_cov_sym_build(hipStream_t st, const double* Xa, const double* Ua, long n, int d, double sf2, double diag_add,
+                           double* out, long ldo) {
+    if (n <= 0) return GPX_OK;
+    if (!gpx_mfma_pair_supported(d)) return GPX_ERR_UNSUPPORTED;
+    MfmaPairArgs g = {};
+    g.Xa = Xa; g.ldxa = gpx_mfma_ldxa(n); g.n = n;
+    g.Ua = Ua; g.ldua = gpx_mfma_ldua(n); g.m = n;
+    g.d = d; g.sf2 = sf2; g.out = out; g.ldo = ldo;
+    const long nblk = (n + 127) / 128;
+    const int tb = kk_of(d) <= 8 ? 64 : 32;
+    int gr = sym_gr(nblk);
+    if (tb == 32 && gr < 1) gr = 1;
+    const long units = sym_units(nblk, gr);
+    if (units > 0x3fffffffL) return GPX_ERR_ARG;
+    const int grid = (int)(units < 2048 ? units : 2048);
+    const long slot = gpx_pair_prof_open(st, 0, 4.0 * (double)n * (double)n);
+#define GPX_COVSYM_CASE(K) case K: hipLaunchKernelGGL((cov_sym_mfma_kernel<K>), dim3(grid), dim3(256), 0, st, g, (int)units, gr, diag_add); break;
+    switch (kk_of(d)) {
+        GPX_COVSYM_CASE(1) GPX_COVSYM_CASE(2) GPX_COVSYM_CASE(3) GPX_COVSYM_CASE(4) GPX_COVSYM_CASE(5) GPX_COVSYM_CASE(6)
+        GPX_COVSYM_CASE(7) GPX_COVSYM_CASE(8) GPX_COVSYM_CASE(9) GPX_COVSYM_CASE(10) GPX_COVSYM_CASE(11) GPX_COVSYM_CASE(12)
+        GPX_COVSYM_CASE(13) GPX_COVSYM_CASE(14) GPX_COVSYM_CASE(15)
+        default: hipLaunchKernelGGL((cov_sym_mfma_kernel<16>), dim3(grid), dim3(256), 0, st, g, (int)units, gr, diag_add); break;
+    }
+#undef GPX_COVSYM_CASE
     gpx_pair_prof_close(st, slot);
     HIP_TRY(hipGetLastError());
     return GPX_OK;
