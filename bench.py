@@ -574,9 +574,10 @@ def main():
                          "algorithmic_flops_per_eval": prof["gemm_flops"],
                          "flops_in_other_gemm_launches_per_eval": prof["small_flops"]},
             "hbm_rooflines": [r for r in (
-                hbm_roofline("cov_build_kernel (K + sn2 I, lower triangle)", prof.get("cov_build"),
-                             "algorithmic bytes = 4 n^2 written; VALU-bound (exp + direct differences), DESIGN.md §3.3",
-                             ("exact_n65536_traffic.json", ("cov_build_kernel",)) if n == 65536 else None),
+                hbm_roofline("kernel-matrix build K + sn2 I, lower triangle (cov_sym_mfma_kernel; cov_build_kernel for d > 62)",
+                             prof.get("cov_build"),
+                             "algorithmic bytes = 4 n^2 written; r2 on the matrix cores, one exp per pair on the vector unit, DESIGN.md §3.3",
+                             ("exact_n65536_traffic.json", ("cov_sym_mfma_kernel", "cov_build_kernel")) if n == 65536 else None),
                 hbm_roofline("gradient trace over (K+sn2 I)^-1 (trace_sym_mfma_kernel / pair_trace_kernel)", prof.get("pair_trace"),
                              "algorithmic bytes = 4 n^2 read",
                              ("exact_n65536_traffic.json", ("trace_sym_mfma_kernel", "pair_trace_kernel")) if n == 65536 else None)) if r],
