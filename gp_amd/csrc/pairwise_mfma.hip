@@ -682,9 +682,32 @@ __global__ __launch_bounds__(256, 2) void trace_sym_mfma_kernel(const MfmaPairAr
             for (int jt = 0; jt < JT; ++jt) acc2[s][jt] = (v4d){0, 0, 0, 0};
         const bool rows_in = row0 + RB <= g.n;
 
+        // the weights of a 16-column group are requested one group ahead (the first group of the next tile across the
+        // tile's barriers): a wave has 4 KB of weights in flight beside the group it works on
+        auto load_w = [&](long tb0, int bt, double (&w)[4][NS]) {
+            const bool tfull = tb0 + TB <= row0 && rows_in && vec;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long b = tb0 + 16 * bt + 4 * r + l4;
+                const double* p1 = g.M1 + a0 + b * g.ldm1;
+                if (tfull) {
+                    if (NS == 2) {
+                        const v2d t = *reinterpret_cast<const v2d*>(p1);
+                        w[r][0] = t.x;
+                        w[r][NS - 1] = t.y;
+                    } else {
+                        w[r][0] = p1[0];
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) w[r][s] = (b <= a0 + s && a0 + s < g.n) ? p1[s] : 0.0;   // lower triangle only
+                }
+            }
+        };
+        double wn[4][NS];
+        if (bfirst < blast) load_w(bfirst, 0, wn);
         for (long b0 = bfirst; b0 < blast; b0 += TB) {
             const bool below = b0 + TB <= row0;                  // the whole tile lies strictly below the diagonal
-            const bool full = below && rows_in && vec;
             __syncthreads();   // the previous tile's fragments are consumed
             stage_u<KK, true>(g, b0, sU, sUT);
             if (threadIdx.x < TB) sv[threadIdx.x] = (g.v && b0 + threadIdx.x < g.n) ? g.v[b0 + threadIdx.x] : 0.0;
@@ -693,22 +716,11 @@ __global__ __launch_bounds__(256, 2) void trace_sym_mfma_kernel(const MfmaPairAr
             for (int bt = 0; bt < TB / 16; ++bt) {
                 double w1[4][NS];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long b = b0 + 16 * bt + 4 * r + l4;
-                    const double* p1 = g.M1 + a0 + b * g.ldm1;
-                    if (full) {
-                        if (NS == 2) {
-                            const v2d t = *reinterpret_cast<const v2d*>(p1);
-                            w1[r][0] = t.x;
-                            w1[r][NS - 1] = t.y;
-                        } else {
-                            w1[r][0] = p1[0];
-                        }
-                    } else {
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) w1[r][s] = (b <= a0 + s && a0 + s < g.n) ? p1[s] : 0.0;   // lower triangle only
-                    }
-                }
+                    for (int s = 0; s < NS; ++s) w1[r][s] = wn[r][s];
+                if (bt + 1 < TB / 16) load_w(b0, bt + 1, wn);
+                else if (b0 + TB < blast) load_w(b0 + TB, 0, wn);
                 v4d D[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) D[s] = (v4d){0, 0, 0, 0};
