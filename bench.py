@@ -145,7 +145,7 @@ def cpu_baseline(d, n_target, fitc_n, fitc_m):
         fn(oracle.COV_SE_ARD, X[:n], y[:n], hyp)
         return time.perf_counter() - t0
 
-    one = {n: t_exact(oracle.exact_nll, n) for n in (1024, 2048, 3072)}          # ~1 + 5 + 16 s
+    one = {n: t_exact(oracle.exact_nll, n) for n in (1024, 2048, 4096)}          # ~0.3 + 2.5 + 35 s (BASELINE.md §2 sizes up to 4096)
     a1 = _fit_power(list(one), list(one.values()), 3)
     # the exponent the measured points themselves follow (log-log least squares): above 3 = the scalar port falling out
     # of cache as n grows, i.e. the a*n^3 extrapolation UNDER-states the port's time at n = 65536 and says nothing

@@ -178,9 +178,11 @@ __global__ __launch_bounds__(256) void potrf_base_tile_kernel(double* __restrict
 //                             columns broadcast with v_readlane);  the panel below it is a forward substitution
 //                             X L_kk^T = S_:k with one row per thread (L_kk read as LDS broadcasts), so that no
 //                             inverse sits on the critical path;  the trailing update  S_ij -= L_ik L_jk^T  is one
-//                             4-MFMA chain per sub-block, with a look-ahead: block column k + 1 first (all 8 waves),
-//                             then wave 0 factors diagonal sub-block k + 1 WHILE waves 1..7 update the rest
-//                             (factor phase 29 us -> 25 us at nb = 128);  3 barriers per k.
+//                             4-MFMA chain per sub-block, with a look-ahead: wave 0 updates and factors diagonal
+//                             sub-block k + 1 WHILE waves 1..7 update block column k + 1 and then the rest
+//                             (factor phase 29 us -> 25 us at nb = 128);  2 barriers per k.  Per k (base_probe):
+//                             panel 1.24 us, wave 0's update + factorisation 1.9 - 2.4 us (270 cycles per pivot: the
+//                             v_readlane broadcasts of a column), the other waves wait 0.08 us for it.
 //   The inverses of the diagonal sub-blocks follow, all at once (one per wave, one column per lane).
 //   W = L^-1 by forward substitution per block column, W_ij = -W_ii sum_{k=j}^{i-1} L_ik W_kj, one block column
 //   per wave with no barrier at all: W_ij is stored in the (unused) upper block (j, i), so that L stays intact.
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
     for (int k = 0; k < nblk; ++k) {
         const int o = 16 * k;
         __syncthreads();   // L_kk and 1 / l_jj are there, and so is every trailing update of the step before
+        BASE_STAMP(8 + 3 * k);
         // ---- panel: X L_kk^T = S_:k by forward substitution, one row of the panel per thread (L_kk as LDS broadcasts):
         // no inverse of the diagonal sub-block on the critical path of the factorisation
         {
@@ -305,18 +308,28 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
             }
         }
         __syncthreads();
+        BASE_STAMP(9 + 3 * k);
         // ---- trailing update with a look-ahead: first the block column k + 1 (all the next diagonal factorisation
         // and the next panel need), then wave 0 factors the next diagonal sub-block WHILE waves 1..7 update the rest
         const int t = nblk - k - 1;
-        for (int q = wv; q < t; q += 8) trail(o, k + 1 + q, k + 1);
-        __syncthreads();
         if (wv == 0) {
-            if (t > 0) chol(o + 16);
+            // the next diagonal sub-block: its own update, then its factorisation, beside the other waves' updates (no
+            // barrier between the block column k + 1 and the rest: nothing below reads what another wave writes here)
+            if (t > 0) {
+                trail(o, k + 1, k + 1);
+                chol(o + 16);
+            }
+            BASE_STAMP(10 + 3 * k);
         } else {
-            for (int p = wv - 1; p < t * (t - 1) / 2; p += 7) {
-                int i = 0, rem = p;   // p -> (i, rem), row-major over the lower triangle of the (t - 1) x (t - 1) blocks right of column k + 1
-                while (rem > i) rem -= ++i;
-                trail(o, k + 2 + i, k + 2 + rem);
+            const int ncol = t - 1;   // block column k + 1 below its diagonal sub-block first (the next panel), then the rest
+            for (int p = wv - 1; p < ncol + t * (t - 1) / 2; p += 7) {
+                if (p < ncol) {
+                    trail(o, k + 2 + p, k + 1);
+                } else {
+                    int i = 0, rem = p - ncol;   // -> (i, rem), row-major over the lower triangle of the (t - 1) x (t - 1) blocks right of column k + 1
+                    while (rem > i) rem -= ++i;
+                    trail(o, k + 2 + i, k + 2 + rem);
+                }
             }
         }
     }

@@ -1,5 +1,5 @@
 // base_probe.hip — phase timing of the 128-row factor-and-invert base kernel (chol.hip) on one random SPD block.
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGPX_BASE_TIMING -I gp_amd/csrc tools/probe/base_probe.hip gp_amd/csrc/gemm_f64.hip gp_amd/csrc/blas1.hip -o tools/probe/base_probe
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGPX_BASE_TIMING -I gp_amd/csrc tools/probe/base_probe.hip gp_amd/csrc/gemm_f64.hip gp_amd/csrc/vecops.hip -o tools/probe/base_probe
 #include "../../gp_amd/csrc/chol.hip"
 #include <cstdlib>
 #include <vector>
@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 3; ++rep) {
         hipMemcpy(dA, A.data(), sizeof(double) * ld * nb, hipMemcpyHostToDevice);
         hipMemset(dW, 0, sizeof(double) * ld * nb);
-        hipLaunchKernelGGL(potrf_inv_base_kernel, dim3(1), dim3(512), 0, 0, dA, (long)ld, nb, dW, (long)ld, dinfo);
+        hipLaunchKernelGGL(potrf_inv_base_kernel<false>, dim3(1), dim3(512), 0, 0, dA, (long)ld, nb, dW, (long)ld, dinfo);
         hipDeviceSynchronize();
         long long t[64] = {0};
 #ifdef GPX_BASE_TIMING
@@ -32,6 +32,10 @@ int main(int argc, char** argv) {
         auto us = [&](int a, int b) { return (t[b] - t[a]) * 0.01; };
         printf("nb %d: load %.2f  factor %.2f  L store %.2f  inverse %.2f  W store %.2f  total %.2f us\n", nb,
                us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(0, 5));
+        if (rep == 2)
+            for (int k = 0; k < (nb + 15) / 16; ++k)   // per sub-block column: panel | wave 0: diagonal update + factorisation | wait for the other waves
+                printf("  k %d: panel %.2f  wave-0 update+chol %.2f  wait %.2f us\n", k, us(8 + 3 * k, 9 + 3 * k), us(9 + 3 * k, 10 + 3 * k),
+                       k + 1 < (nb + 15) / 16 ? us(10 + 3 * k, 11 + 3 * k) : 0.0);
     }
     if (argc > 2) {   // accuracy on an ill-conditioned kernel matrix (nb <= 64): new and old base kernels against long double
         const int n = nb <= 64 ? nb : 64;
@@ -60,7 +64,7 @@ int main(int argc, char** argv) {
         for (int which = 0; which < 2; ++which) {
             hipMemcpy(dA, K.data(), sizeof(double) * ld * n, hipMemcpyHostToDevice);
             hipMemset(dW, 0, sizeof(double) * ld * nb);
-            if (which == 0) hipLaunchKernelGGL(potrf_inv_base_kernel, dim3(1), dim3(512), 0, 0, dA, (long)ld, n, dW, (long)ld, dinfo);
+            if (which == 0) hipLaunchKernelGGL(potrf_inv_base_kernel<false>, dim3(1), dim3(512), 0, 0, dA, (long)ld, n, dW, (long)ld, dinfo);
             else hipLaunchKernelGGL(potrf_base_tile_kernel, dim3(1), dim3(256), 0, 0, dA, (long)ld, n, dW, (long)ld, 0, dinfo);
             hipDeviceSynchronize();
             std::vector<double> L((size_t)ld * n), W((size_t)ld * n);
