@@ -499,6 +499,9 @@ def run_config0(lib, with_cpu=True):
             wall = time.perf_counter() - t0
             mle = {"command": "gp 8000 (MLE from the default hypers, maxeval 160 (GP.cpp:232), _setK, batch_predict of 2000 points, pred file)",
                    "returncode": pr.returncode, "process_wall_s": wall}
+            if pr.returncode != 0:   # say why (the child's last words), never hide it
+                mle["stderr_tail"] = pr.stderr[-800:]
+                mle["stdout_tail"] = pr.stdout[-400:]
             for key, pat in (("training_time_s", r"Training time: ([0-9.eE+-]+)"), ("prediction_time_s", r"Prediction time: ([0-9.eE+-]+)"),
                              ("final_nll", r"Negative log likelihood: ([0-9.eE+-]+)")):
                 mm = re.search(pat, pr.stdout)
