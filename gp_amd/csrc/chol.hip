@@ -199,8 +199,10 @@ constexpr int LDW = 17;        // leading dimension of the 16 x 16 diagonal inve
 #ifdef GPX_BASE_TIMING             // tools/probe/base_probe.hip: 100 MHz time stamps of the kernel's phases
 __device__ long long g_base_t[64];
 #define BASE_STAMP(i) do { if (threadIdx.x == 0) g_base_t[i] = wall_clock64(); } while (0)
+#define BASE_STAMP_WAVE(i) do { if ((threadIdx.x & 63) == 0) g_base_t[i] = wall_clock64(); } while (0)
 #else
 #define BASE_STAMP(i) do { } while (0)
+#define BASE_STAMP_WAVE(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {   // lane: wave-uniform
@@ -236,6 +238,8 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
         }
     }
     bool bad = false;
+    const bool lvec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 2 == 0);   // 16-byte stores of L / W are aligned
+    const bool wvec = ((reinterpret_cast<uintptr_t>(W) & 15) == 0) && (ldw % 2 == 0);
     auto chol = [&](int o) {   // wave 0 only
         // ---- Cholesky of the 16 x 16 diagonal sub-block: lane i (and its three copies) holds row i
         double r[16];
@@ -281,6 +285,49 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
 #pragma unroll
         for (int r = 0; r < 4; ++r) S[(16 * bi + l4 + 4 * r) + (16 * bj + l15) * LDI] = D[r];
     };
+    // x <- the forward substitution with the 16 x 16 diagonal sub-block at o:  x[j] = (x[j] - sum_{q<j} x[q] L_jq) / l_jj  (a row of
+    // the panel times L_kk^-T, or a column of L_kk^-1 from a unit vector).  L_kk is read in two batches (columns 0-7 of rows
+    // 1-7; then of rows 8-15 together with columns 8-15), each requested in full BEFORE the arithmetic that uses it: left to
+    // itself the compiler reads every entry right before its multiply-add, one exposed LDS round trip per entry (panel 1.24 ->
+    // 0.8 us per sub-block column; same operations in the same order)
+    auto fwd16 = [&](int o, double (&x)[16], bool divide) {
+        double dg[8], l1[8][8], l2[8][8], l3[8][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dg[j] = divide ? S[(o + j) + (o + j) * LDI] : invd[o + j];
+#pragma unroll
+            for (int c = j + 1; c < 8; ++c) l1[j][c] = S[(o + c) + (o + j) * LDI];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x[j] = divide ? x[j] / dg[j] : x[j] * dg[j];
+#pragma unroll
+            for (int c = j + 1; c < 8; ++c) x[c] = fma(-x[j], l1[j][c], x[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) l2[j][c] = S[(o + 8 + c) + (o + j) * LDI];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dg[j] = divide ? S[(o + 8 + j) + (o + 8 + j) * LDI] : invd[o + 8 + j];
+#pragma unroll
+            for (int c = j + 1; c < 8; ++c) l3[j][c] = S[(o + 8 + c) + (o + 8 + j) * LDI];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[8 + c] = fma(-x[j], l2[j][c], x[8 + c]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x[8 + j] = divide ? x[8 + j] / dg[j] : x[8 + j] * dg[j];
+#pragma unroll
+            for (int c = j + 1; c < 8; ++c) x[8 + c] = fma(-x[8 + j], l3[j][c], x[8 + c]);
+        }
+    };
     __syncthreads();
     BASE_STAMP(1);
     if (wv == 0) chol(0);
@@ -296,13 +343,7 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
                 double x[16];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) x[c] = S[row + (o + c) * LDI];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    if (XP) x[j] /= S[(o + j) + (o + j) * LDI];
-                    else x[j] *= invd[o + j];
-#pragma unroll
-                    for (int c = j + 1; c < 16; ++c) x[c] = fma(-x[j], S[(o + c) + (o + j) * LDI], x[c]);
-                }
+                fwd16(o, x, XP);
 #pragma unroll
                 for (int c = 0; c < 16; ++c) S[row + (o + c) * LDI] = x[c];
             }
@@ -331,23 +372,45 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
                     trail(o, k + 2 + i, k + 2 + rem);
                 }
             }
+            // block column k of L is final since the panel: waves 1-7 store it (lower triangle, rows < nb; two adjacent rows
+            // per lane, 16-byte stores) in the time they would otherwise wait for wave 0's factorisation
+            v2d v[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int e = min(tid - 64 + 448 * m, 1023);
+                v[m] = *reinterpret_cast<const v2d*>(&S[2 * (e & 63) + (o + (e >> 6)) * LDI]);
+            }
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int e = tid - 64 + 448 * m, r = 2 * (e & 63), c = o + (e >> 6);
+                if (e < 1024) {
+                    double* ap = A + r + (long)c * lda;
+                    if (lvec && c <= r && r + 1 < nb) {
+                        *reinterpret_cast<v2d*>(ap) = v[m];
+                    } else {
+                        if (c <= r && r < nb) ap[0] = v[m].x;
+                        if (c <= r + 1 && r + 1 < nb) ap[1] = v[m].y;
+                    }
+                }
+            }
         }
     }
     __syncthreads();
     BASE_STAMP(2);
     if (bad) *info = 1;
-    // ---- inverses of the diagonal sub-blocks, all at once (wave k: sub-block k): lane c solves L_kk w = e_c with L_kk
-    // as LDS broadcasts, right-looking so that two dependent operations per row are on the critical path
+    // ---- inverses of the diagonal sub-blocks, all at once (wave k: sub-block k): lane c solves L_kk w = e_c
     for (int k = wv; k < nblk; k += 8) {
-        const int o = 16 * k;
         double w[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) w[i] = (i == l15) ? 1.0 : 0.0;
+        {
+            const int o = 16 * k;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            w[q] *= invd[o + q];
+            for (int q = 0; q < 16; ++q) {
+                w[q] *= invd[o + q];
 #pragma unroll
-            for (int i = q + 1; i < 16; ++i) w[i] = fma(-S[(o + i) + (o + q) * LDI], w[q], w[i]);
+                for (int i = q + 1; i < 16; ++i) w[i] = fma(-S[(o + i) + (o + q) * LDI], w[q], w[i]);
+            }
         }
         if (lane < 16) {
 #pragma unroll
@@ -355,61 +418,85 @@ __global__ __launch_bounds__(512) void potrf_inv_base_kernel(double* __restrict_
         }
     }
     __syncthreads();
-    {   // L: all LDS reads of a thread first, then its stores (a read - wait - store loop pays one LDS round trip and a
-        // 64-bit address multiply per element, 32 in a row: 3.9 us; so did the W store below: 3.2 us)
-        const int r = tid & (NBI - 1), c0 = tid >> 7;
-        double v[NBI * NBI / 512];
+    BASE_STAMP(3);
+    // ---- the diagonal sub-blocks of W (wave k: sub-block k; zero above the diagonal is the caller's contract)
+    if (wv < nblk) {
 #pragma unroll
-        for (int q = 0; q < NBI * NBI / 512; ++q) v[q] = S[r + (c0 + 4 * q) * LDI];
-        double* ap = A + r + (long)c0 * lda;
-        const long step = 4 * lda;
-#pragma unroll
-        for (int q = 0; q < NBI * NBI / 512; ++q) {
-            if (r < nb && c0 + 4 * q <= r) *ap = v[q];
-            ap += step;
+        for (int q = 0; q < 4; ++q) {
+            const int row = 16 * wv + l15, col = 16 * wv + l4 + 4 * q;
+            if (row < nb && col <= row) W[row + (long)col * ldw] = Wd[wv][l15 + (l4 + 4 * q) * LDW];
         }
     }
-    BASE_STAMP(3);
-    // ---- W = L^-1: block column j on wave j; W_ij (i > j) goes to the upper block (j, i), L stays intact
-    for (int j = wv; j < nblk; j += 8) {
-        for (int i = j + 1; i < nblk; ++i) {
-            v4d D = {0, 0, 0, 0};
-            for (int q = j; q < i; ++q) {
+    // ---- W = L^-1 below the diagonal sub-blocks: block column w on wave w < 4, block column 11 - w on wave w >= 4 (waves w and
+    // w + 4 share a SIMD: 168 + 0, 132 + 12, 100 + 28, 72 + 48 MFMAs per SIMD); W_ij (i > j) is parked in the upper block (j, i) of
+    // the LDS image, L stays intact.  Right-looking within a block column: as soon as W_qj is known every row block below
+    // it takes D_i += L_iq W_qj (one 4-MFMA chain per row block, independent of one another, all operands of the step
+    // requested before its first MFMA), then W_(q+1)j = -W_(q+1)(q+1) D_(q+1).  The left-looking form (all of D_i, then W_ij,
+    // one row block after the other, every operand read right before its MFMA) took 122 cycles per MFMA: 8.3 us for block
+    // column 0.  Same sums in the same order.  Each wave stores its own blocks from the parked copy (rows along the lanes) one
+    // step after it formed them, beside the next step's MFMAs: no store phase of its own.
+    // block (j + 1 + ii, j) of W from its parked copy: element (16 i + a, 16 j + b) sits at S[(16 j + a) + (16 i + b) LDI]
+    auto store_w = [&](int j, int ii) {
+        const int a = 2 * (lane & 7), b0 = lane >> 3, i = j + 1 + ii;   // rows a, a + 1 of the block; columns b0, b0 + 8
+        v2d v[2];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const double b = (q == j) ? Wd[j][(4 * kk + l4) + l15 * LDW] : S[(16 * j + 4 * kk + l4) + (16 * q + l15) * LDI];
-                    D = mfma16(S[(16 * i + l15) + (16 * q + 4 * kk + l4) * LDI], b, D);
+        for (int h = 0; h < 2; ++h) v[h] = *reinterpret_cast<const v2d*>(&S[(16 * j + a) + (16 * i + b0 + 8 * h) * LDI]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = 16 * i + a, col = 16 * j + b0 + 8 * h;
+            double* wp = W + row + (long)col * ldw;
+            if (wvec && row + 1 < nb) {
+                *reinterpret_cast<v2d*>(wp) = v[h];
+            } else {
+                if (row < nb) wp[0] = v[h].x;
+                if (row + 1 < nb) wp[1] = v[h].y;
+            }
+        }
+    };
+    {
+        const int j = wv < 4 ? wv : 11 - wv;
+        if (j < nblk - 1) {
+            v4d D[7];
+#pragma unroll
+            for (int ii = 0; ii < 7; ++ii) D[ii] = (v4d){0, 0, 0, 0};
+#pragma unroll
+            for (int st = 0; st < 7; ++st) {   // step st: q = j + st, row blocks i = j + 1 + ii with ii >= st
+                const int q = j + st;
+                if (q < nblk - 1) {
+                    double bq[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        bq[kk] = (st == 0) ? Wd[j][(4 * kk + l4) + l15 * LDW] : S[(16 * j + 4 * kk + l4) + (16 * q + l15) * LDI];
+                    double aq[7][4];
+#pragma unroll
+                    for (int ii = st; ii < 7; ++ii)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            aq[ii][kk] = S[(16 * min(j + 1 + ii, nblk - 1) + l15) + (16 * q + 4 * kk + l4) * LDI];
+                    if (st > 0) store_w(j, st - 1);   // the block parked one step ago goes to memory beside this step's MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int ii = st; ii < 7; ++ii)
+                            if (j + 1 + ii < nblk) D[ii] = mfma16(aq[ii][kk], bq[kk], D[ii]);
+                    // -W_ii * D: D's rows (l4 + 4 r) are the contraction index of the second product, taken in that order
+                    const int i = q + 1;
+                    v4d R = {0, 0, 0, 0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) R = mfma16(-Wd[i][l15 + (l4 + 4 * r) * LDW], D[st][r], R);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) S[(16 * j + l4 + 4 * r) + (16 * i + l15) * LDI] = R[r];
                 }
             }
-            // -W_ii * D: D's rows (l4 + 4 r) are the contraction index of the second product, taken in that order
-            v4d R = {0, 0, 0, 0};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) R = mfma16(-Wd[i][l15 + (l4 + 4 * r) * LDW], D[r], R);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) S[(16 * j + l4 + 4 * r) + (16 * i + l15) * LDI] = R[r];
+            store_w(j, nblk - 2 - j);   // the last block of the column
         }
     }
-    __syncthreads();
+    BASE_STAMP_WAVE(40 + wv);   // end of this wave's share of the block inverse
+#ifdef GPX_BASE_TIMING
+    if (lane == 0) g_base_t[50 + wv] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: SIMD of this wave in bits 5:4
+#endif
     BASE_STAMP(4);
-    {
-        const int r = tid & (NBI - 1), c0 = tid >> 7, br = r >> 4;
-        double v[NBI * NBI / 512];
-#pragma unroll
-        for (int q = 0; q < NBI * NBI / 512; ++q) {
-            const int c = c0 + 4 * q, bc = c >> 4;
-            // diagonal sub-block: Wd (zero above its diagonal); below: W_ij parked in the upper block (j, i); above: unused
-            const double* src = (br == bc) ? &Wd[br][(r & 15) + (c & 15) * LDW]
-                                           : &S[(16 * min(bc, br) + (r & 15)) + (16 * br + (c & 15)) * LDI];
-            v[q] = *src;
-        }
-        double* wp = W + r + (long)c0 * ldw;
-        const long step = 4 * ldw;
-#pragma unroll
-        for (int q = 0; q < NBI * NBI / 512; ++q) {
-            if (r < nb && c0 + 4 * q <= r) *wp = v[q];   // W is zero above the diagonal on entry (contract of gpx_potrf_inv)
-            wp += step;
-        }
-    }
     BASE_STAMP(5);
 }
 

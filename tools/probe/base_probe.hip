@@ -30,8 +30,15 @@ int main(int argc, char** argv) {
         hipMemcpyFromSymbol(t, HIP_SYMBOL(g_base_t), sizeof(t));
 #endif
         auto us = [&](int a, int b) { return (t[b] - t[a]) * 0.01; };
-        printf("nb %d: load %.2f  factor %.2f  L store %.2f  inverse %.2f  W store %.2f  total %.2f us\n", nb,
+        printf("nb %d: load %.2f  factor %.2f  diagonal inverses %.2f  block inverse | L store %.2f  W store %.2f  total %.2f us\n", nb,
                us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(0, 5));
+        if (rep == 2) {
+            printf("  block inverse + W store of waves 0-7 done after");
+            for (int w = 0; w < 8; ++w) printf(" %.2f", us(3, 40 + w));
+            printf(" us; SIMD of waves 0-7:");
+            for (int w = 0; w < 8; ++w) printf(" %lld", (t[50 + w] >> 4) & 3);
+            printf("\n");
+        }
         if (rep == 2)
             for (int k = 0; k < (nb + 15) / 16; ++k)   // per sub-block column: panel | wave 0: diagonal update + factorisation | wait for the other waves
                 printf("  k %d: panel %.2f  wave-0 update+chol %.2f  wait %.2f us\n", k, us(8 + 3 * k, 9 + 3 * k), us(9 + 3 * k, 10 + 3 * k),
