@@ -181,16 +181,19 @@ __global__ __launch_bounds__(256) void potrf_base_tile_kernel(double* __restrict
 //                             4-MFMA chain per sub-block, with a look-ahead: wave 0 updates and factors diagonal
 //                             sub-block k + 1 WHILE waves 1..7 update block column k + 1 and then the rest
 //                             (factor phase 29 us -> 25 us at nb = 128);  2 barriers per k.  Per k (base_probe):
-//                             panel 1.24 us, wave 0's update + factorisation 1.9 - 2.4 us (270 cycles per pivot: the
+//                             panel 0.8 us (1.24 before its LDS reads were batched), wave 0's update + factorisation 1.9 - 2.4 us (270 cycles per pivot: the
 //                             v_readlane broadcasts of a column), the other waves wait 0.08 us for it.
+//                             Waves 1..7 store block column k of L to memory while they wait for wave 0 (no store phase).
 //   The inverses of the diagonal sub-blocks follow, all at once (one per wave, one column per lane).
-//   W = L^-1 by forward substitution per block column, W_ij = -W_ii sum_{k=j}^{i-1} L_ik W_kj, one block column
-//   per wave with no barrier at all: W_ij is stored in the (unused) upper block (j, i), so that L stays intact.
+//   W = L^-1 below the diagonal sub-blocks: block column w on wave w < 4, 11 - w on wave w >= 4 (waves w, w + 4 share a SIMD),
+//   right-looking inside the column (W_qj known -> every D_i += L_iq W_qj, independent 4-MFMA chains whose operands are all
+//   requested before the first MFMA; then W_(q+1)j = -W_(q+1)(q+1) D_(q+1)), no barrier at all: W_ij is parked in the (unused)
+//   upper block (j, i) so that L stays intact, and stored to memory by the same wave one step later, beside the next step's
+//   MFMAs.  (Left-looking with every operand read right before its MFMA: 122 cycles per MFMA, 8.3 us for block column 0.)
 // (The block inverse by recursive doubling over the sub-blocks - T = L21 W11, W21 = -W22 T per level, at most 12 dependent
-// block products instead of 35 - was written and measured: 7.8 us against 8.2 us, each product is bound by its LDS round
-// trip and four dependent MFMAs whatever the chain length; not kept.)
+// block products instead of 35 - was written and measured: 7.8 us against 8.2 us at the time; not kept.)
 // Replaces, per 128 rows, two launches of the 64 x 64 kernel above and four single-tile GEMM launches (74 us ->
-// 43 us, phases: tools/probe/base_probe.hip): the serial chain of small launches is what bounds exact n <= 8192 and the replicated m x m
+// 43 us at the end of round 2, 37 us now; phases: tools/probe/base_probe.hip): the serial chain of small launches is what bounds exact n <= 8192 and the replicated m x m
 // phase of the sparse models.  Contract as potrf_base_tile_kernel(..., wfull = 0): A's lower triangle <- L,
 // W (nb x nb) <- L^-1 with zeros above the diagonal, *info = 1 on a pivot <= 0 (Eigen::LLT NumericalIssue).
 constexpr int NBI = 128;       // rows of the base block
