@@ -495,7 +495,18 @@ def run_config0(lib, with_cpu=True):
             np.savetxt(os.path.join(td, "train_y"), yall, fmt="%.17g")
             np.savetxt(os.path.join(td, "test_x"), Xs, fmt="%.17g")
             t0 = time.perf_counter()
-            pr = subprocess.run([exe, "8000"], cwd=td, capture_output=True, text=True, timeout=600)
+            # Under `rocprofv3 -- python3 bench.py` the profiler's tool library would be injected into this child as well; its
+            # initialisation thread crashed there (SIGSEGV inside the tool, twice in three profiled runs of the default
+            # workload; never without the profiler).  The child is a program of its own, not part of the profiled process:
+            # it runs without the profiler's entries (nothing else of the environment is touched).
+            cenv = {k: v for k, v in os.environ.items()
+                    if not (k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER")) or k in ("HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE"))}
+            if "LD_PRELOAD" in cenv:
+                keep = [e for e in cenv["LD_PRELOAD"].replace(":", " ").split() if "rocprof" not in e.lower()]
+                cenv["LD_PRELOAD"] = ":".join(keep)
+                if not keep:
+                    del cenv["LD_PRELOAD"]
+            pr = subprocess.run([exe, "8000"], cwd=td, capture_output=True, text=True, timeout=600, env=cenv)
             wall = time.perf_counter() - t0
             mle = {"command": "gp 8000 (MLE from the default hypers, maxeval 160 (GP.cpp:232), _setK, batch_predict of 2000 points, pred file)",
                    "returncode": pr.returncode, "process_wall_s": wall}
