@@ -238,7 +238,17 @@ class Dist:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(ext):
             e0.record(ext)
+            if self.backend == "gloo":
+                # gloo (rehearsals on one GPU, never the measured path) reduces on the host: it stages the tensor through a
+                # pool stream that waits for this one and then blocks the host.  With m = 1024 both ranks of a shared-GPU
+                # rehearsal sat in that wait for good while the library's stream itself drains at once when it is
+                # waited for directly (tools/dist_rehearsal.py REH_SYNC=1, profiles/r03_dist_rehearsal.log) - so drain it
+                # here first; the NCCL path below stays stream-ordered, the host does not block.
+                trace("hook: draining the library stream", count)
+                ext.synchronize()
+            trace("hook: all-reduce", count)
             self.dist.all_reduce(t)
+            trace("hook: all-reduce returned")
             e1.record(ext)
         self.hook_events.append((e0, e1, count))
 
