@@ -27,6 +27,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -623,6 +624,23 @@ def main():
     for model in ("fitc", "vfe"):
         if model not in want:
             continue
+        # world > 1: the sharded legs hold the only collectives of the run.  If one of them does not come back (a peer that
+        # died, a stalled collective), rank 0 still prints the line with everything measured so far - the exact-GP value the
+        # metric is quoted on - and the leg marked as timed out, and every rank leaves; nothing is reported as measured
+        # that was not.  GPX_BENCH_LEG_TIMEOUT seconds per leg (default 300; a leg takes a few seconds).
+        guard = None
+        if D.world > 1 and "value" in out:
+            def give_up(model=model):
+                out[model] = {"error": f"the sharded {model} leg did not finish within {leg_timeout:g} s on {D.world} ranks; "
+                                       "not measured"}
+                trace("leg timed out", model)
+                if D.rank == 0:
+                    os.write(json_fd, (json.dumps(out) + "\n").encode())
+                os._exit(0)
+            leg_timeout = float(os.environ.get("GPX_BENCH_LEG_TIMEOUT", "300"))
+            guard = threading.Timer(leg_timeout, give_up)
+            guard.daemon = True
+            guard.start()
         n, m, d = (args.fitc_n, args.fitc_m, args.d) if model == "fitc" else (args.vfe_n, args.vfe_m, args.vfe_d)
         default_size = (n, m, d) == ((1 << 20, 1024, 20) if model == "fitc" else (1 << 22, 2048, 50))
         sp_steps = args.sparse_steps if model == "fitc" else args.vfe_steps
@@ -650,6 +668,8 @@ def main():
         if t1 is not None:
             sub["t1_ms_single_gpu_same_run"] = 1e3 * t1
             sub["parallel_efficiency"] = t1 / (D.world * dt / sp_steps)
+        if guard is not None:
+            guard.cancel()
         out[model] = sub
         if "value" not in out:
             out.update({"value": sub["value"], "ms_per_step": sub["ms_per_step"], "scaling": "strong",
