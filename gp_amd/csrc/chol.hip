@@ -665,14 +665,16 @@ int potrf_inv_rec(hipStream_t st, long n, double* A, long lda, double* W, long l
     // L21 = A21 * W11^T   (B(n,k) = W11[n + k*ldw], zero for k > n)
     rc = gpx_gemm(st, 0, 0, n2, n1, n1, 1.0, A + n1, lda, W, ldw, 0.0, W21, ldw, GEMM_KHI_N);
     if (rc) return rc;
-    rc = gpx_gemm(st, 0, 0, n2, n2, n1, -1.0, W21, ldw, W21, ldw, 1.0, A + n1 + n1 * lda, lda, GEMM_LOWER);
+    // A22 -= L21 L21^T and T = L21 W11 both wait for L21 only: ONE launch below 4096 rows (gpx_gemm_pair), where a product
+    // is a few workgroups bound by the launch-to-launch step.  T lives in the A21 block (off-diagonal blocks of A are
+    // scratch by contract) until the recursion on A22 has delivered W22.
+    double* T21 = A + n1;
+    rc = gpx_gemm_pair(st, n2, n2, n1, -1.0, W21, ldw, W21, ldw, 1.0, A + n1 + n1 * lda, lda, GEMM_LOWER,
+                       n2, n1, n1, 1.0, W21, ldw, W, ldw, 0.0, T21, lda, GEMM_KLO_N);
     if (rc) return rc;
     rc = potrf_inv_rec(st, n2, A + n1 + n1 * lda, lda, W22, ldw, T, info);
     if (rc) return rc;
-    const long ldt = gpx_ld(n2);
-    rc = gpx_gemm(st, 0, 1, n2, n1, n1, 1.0, W21, ldw, W, ldw, 0.0, T, ldt, GEMM_KLO_N);  // T = L21 W11
-    if (rc) return rc;
-    return gpx_gemm(st, 0, 1, n2, n1, n2, -1.0, W22, ldw, T, ldt, 0.0, W21, ldw, GEMM_KHI_M | GEMM_HEAVY_LAST);
+    return gpx_gemm(st, 0, 1, n2, n1, n2, -1.0, W22, ldw, T21, lda, 0.0, W21, ldw, GEMM_KHI_M | GEMM_HEAVY_LAST);
 }
 
 int trsm_left_rec(hipStream_t st, long n, long nrhs, const double* L, long ldl, const double* Wd, double* B,

@@ -249,7 +249,7 @@ __device__ __forceinline__ double sfrag(const double* __restrict__ s, int row, i
 }
 
 template <int TM, int TN, bool AKC, bool BKC, int RD = 0, int SK = 0>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int block) {
     constexpr int NT = 256;
     constexpr int BM = 32 * TM, BN = 32 * TN;
     constexpr int NLA = BM * 8 / NT, NLB = BN * 8 / NT;  // 16-B loads per thread and operand tile
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 
     int bi, bj, ks;
     bool desc;
-    if (!tile_of_block(g, blockIdx.x, bi, bj, ks, desc)) return;
+    if (!tile_of_block(g, block, bi, bj, ks, desc)) return;
     const int m0 = __builtin_amdgcn_readfirstlane(bi * BM), n0 = __builtin_amdgcn_readfirstlane(bj * BN);
 
     int klo = 0, khi = g.K;
@@ -743,6 +743,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     if (RD == 1 || RD == 2) rowdot_epilogue<TM, TN, false, RD>(g, gE, acc, m0 + wm, n0 + wn, part, l15, l4);   // a part without columns gets zeros
 }
 
+template <int TM, int TN, bool AKC, bool BKC, int RD = 0, int SK = 0>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+    gemm_body<TM, TN, AKC, BKC, RD, SK>(g, (int)blockIdx.x);
+}
+
+// TWO independent small products in ONE launch: workgroups [0, grid0) run the first (M/N-contiguous operands), the rest the
+// second (B K-contiguous).  The node of the factor-and-invert recursion uses it for A22 -= L21 L21^T and T = L21 W11, which
+// both wait for L21 only: below 4096 rows such products are a few workgroups bound by the launch-to-launch step, not by
+// the matrix pipe, so two of them side by side cost what one does (chol.hip potrf_inv_rec).
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_pair_kernel(const GemmArgs g0, const GemmArgs g1, const int grid0) {
+    if ((int)blockIdx.x < grid0) gemm_body<TM, TN, false, false>(g0, (int)blockIdx.x);
+    else gemm_body<TM, TN, false, true>(g1, (int)blockIdx.x - grid0);
+}
+
 __global__ void splitk_reduce_kernel(double* __restrict__ C, long ldc, const double* __restrict__ W,
                                      long slab, int splitk, int M, int N, double beta, int lower_bt) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -799,10 +814,17 @@ double useful_flops(long M, long N, long K, int flags) {
     return f;
 }
 
+struct GemmDeferred {   // a product gemm_impl has planned but not launched
+    GemmArgs g;
+    int bt, grid, a_kc, b_kc;
+    bool ready;
+};
+
 int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
               const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
               int flags, int splitk, double* work, const double* kscale = nullptr, const GemmRowdot* rd = nullptr,
-              const GemmPanels* pn = nullptr) {
+              const GemmPanels* pn = nullptr, GemmDeferred* defer = nullptr) {
+    if (defer) defer->ready = false;
     if (M <= 0 || N <= 0) return GPX_OK;
     int kper = 0;
     if (pn) {
@@ -882,6 +904,16 @@ int gemm_impl(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double
             g_prof.skipped_flops += fl;
             g_prof.skipped++;
         }
+    }
+    if (defer && !timed && !band && g.splitk == 1 && !g.R1 && !opdot && !kscale && bt <= 64) {
+        // a plain small product: the caller launches it together with another one (gemm_pair_kernel)
+        defer->g = g;
+        defer->bt = bt;
+        defer->grid = (int)grid;
+        defer->a_kc = a_kc;
+        defer->b_kc = b_kc;
+        defer->ready = true;
+        return GPX_OK;
     }
     const int sk = bt == 128 ? half_skip_kind(flags) : 0;
     if (opdot) hipLaunchKernelGGL((gemm_kernel<4, 4, false, false, 3>), dim3((unsigned)grid), dim3(256), 0, st, g);
@@ -1005,6 +1037,41 @@ int gpx_gemm(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double 
              const double* A, long lda, const double* B, long ldb, double beta, double* C, long ldc,
              int flags, const GemmPanels* pn) {
     return gemm_impl(st, a_kc, b_kc, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags, 1, nullptr, nullptr, nullptr, pn);
+}
+
+// C0 = alpha0 A0 B0^T + beta0 C0 (all operands M/N-contiguous) and C1 = alpha1 A1 op(B1)^T + beta1 C1 (B1 K-contiguous), two
+// independent products.  One launch when both are plain small products on the same tile size, two launches otherwise.
+int gpx_gemm_pair(hipStream_t st, long M0, long N0, long K0, double alpha0, const double* A0, long lda0, const double* B0, long ldb0,
+                  double beta0, double* C0, long ldc0, int flags0, long M1, long N1, long K1, double alpha1, const double* A1,
+                  long lda1, const double* B1, long ldb1, double beta1, double* C1, long ldc1, int flags1) {
+    static const bool off = getenv("GPX_NO_GEMM_PAIR") != nullptr;   // A/B switch
+    GemmDeferred d0, d1;
+    d0.ready = d1.ready = false;
+    int rc = off ? GPX_OK : gemm_impl(st, 0, 0, M0, N0, K0, alpha0, A0, lda0, B0, ldb0, beta0, C0, ldc0, flags0, 1, nullptr, nullptr, nullptr, nullptr, &d0);
+    if (rc) return rc;
+    if (d0.ready) {
+        rc = gemm_impl(st, 0, 1, M1, N1, K1, alpha1, A1, lda1, B1, ldb1, beta1, C1, ldc1, flags1, 1, nullptr, nullptr, nullptr, nullptr, &d1);
+        if (rc) return rc;
+        static const long max_grid = [] { const char* e = getenv("GPX_PAIR_MAX_GRID"); return e ? atol(e) : 2048L; }();   // beyond that the halved occupancy of the pair (46 KB of LDS) costs more than a launch (exact n = 8192: 13.30 ms unpaired, 12.85 with the limit at 2048, 12.95 without limit)
+        if (d1.ready && d1.bt == d0.bt && (long)d0.grid + d1.grid <= max_grid) {
+            const unsigned grid = (unsigned)(d0.grid + d1.grid);
+            if (d0.bt == 32) hipLaunchKernelGGL((gemm_pair_kernel<1, 1>), dim3(grid), dim3(256), 0, st, d0.g, d1.g, d0.grid);
+            else hipLaunchKernelGGL((gemm_pair_kernel<2, 2>), dim3(grid), dim3(256), 0, st, d0.g, d1.g, d0.grid);
+            HIP_TRY(hipGetLastError());
+            return GPX_OK;
+        }
+        // not a pair after all: the first product was only planned, the second launched itself unless it was deferred too
+        rc = gemm_impl(st, 0, 0, M0, N0, K0, alpha0, A0, lda0, B0, ldb0, beta0, C0, ldc0, flags0, 1, nullptr);
+        if (rc) return rc;
+        if (!d1.ready) return GPX_OK;
+        return gemm_impl(st, 0, 1, M1, N1, K1, alpha1, A1, lda1, B1, ldb1, beta1, C1, ldc1, flags1, 1, nullptr);
+    }
+    if (off || M0 <= 0 || N0 <= 0) {   // (an empty first product returns without planning anything)
+        rc = gemm_impl(st, 0, 0, M0, N0, K0, alpha0, A0, lda0, B0, ldb0, beta0, C0, ldc0, flags0, 1, nullptr);
+        if (rc) return rc;
+    }
+    // the first product launched itself inside its planning call (too large, timed, banded ...): the second follows alone
+    return gemm_impl(st, 0, 1, M1, N1, K1, alpha1, A1, lda1, B1, ldb1, beta1, C1, ldc1, flags1, 1, nullptr);
 }
 
 int gpx_gemm_rowdot(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha, const double* A, long lda,

@@ -57,6 +57,11 @@ int gpx_gemm(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double 
 // (>= splitk*M*N doubles), then a deterministic reduction.  work may be NULL -> plain gemm.
 // kscale (optional, K-contiguous A only, 16-B aligned): C = alpha * op(A) diag(kscale) op(B)^T + beta*C,
 // the weighted Gram products K^T diag(g) K of the sparse models without a scaled copy of K.
+// two independent products, one launch where both are plain small ones (gemm_f64.hip gemm_pair_kernel): the first with
+// M/N-contiguous operands, the second with a K-contiguous B
+int gpx_gemm_pair(hipStream_t st, long M0, long N0, long K0, double alpha0, const double* A0, long lda0, const double* B0, long ldb0,
+                  double beta0, double* C0, long ldc0, int flags0, long M1, long N1, long K1, double alpha1, const double* A1,
+                  long lda1, const double* B1, long ldb1, double beta1, double* C1, long ldc1, int flags1);
 int gpx_gemm_splitk(hipStream_t st, int a_kc, int b_kc, long M, long N, long K, double alpha,
                     const double* A, long lda, const double* B, long ldb, double beta, double* C,
                     long ldc, int flags, double* work, long work_doubles, const double* kscale = nullptr,
