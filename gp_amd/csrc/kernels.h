@@ -68,8 +68,8 @@ int gpx_mfma_sym_trace(hipStream_t st, const double* Xa, const double* Ua, const
 // ld 64) receives the inverse of every 64x64 diagonal base block; *info (device int, must be 0
 // on entry) is set to 1 when a pivot is not positive.
 int gpx_potrf(hipStream_t st, long n, double* A, long lda, double* Wd, int* info);
-// Factor AND invert: diagonal blocks of A <- those of L (off-diagonal blocks of A are scratch),
-// W <- L^-1.  W must be zero above the diagonal on entry; T as for gpx_trtri.
+// Factor AND invert: diagonal blocks of A <- those of L (off-diagonal blocks of A are scratch: each node keeps
+// T = L21 W11 in its A21 block), W <- L^-1.  W must be zero above the diagonal on entry; T is no longer used.
 int gpx_potrf_inv(hipStream_t st, long n, double* A, long lda, double* W, long ldw, double* T, int* info);
 // W = L^-1 (lower, n x n, ld ldw; W must be zero above the diagonal on entry), T scratch of
 // gpx_trtri_scratch(n) doubles.
