@@ -84,6 +84,15 @@ int64_t gpx_dgemm_splitk_panel_rows(int64_t M, int64_t N, int64_t K, int flags, 
     return gpx_gemm_splitk_panel_rows(M, N, K, flags, work_doubles);
 }
 
+// measurement / test entry (not in gpx.h): the two products of a recursion node as gpx_potrf_inv issues them, C0 = C0 - L L^T on the
+// lower tiles (L: n2 x n1) and C1 = L W (W: n1 x n1 lower triangular, K-contiguous), in one launch where gpx_gemm_pair pairs them
+int gpx_dgemm_pair_node(int64_t n2, int64_t n1, const double* L, int64_t ldl, const double* W, int64_t ldw, double* C0, int64_t ldc0,
+                        double* C1, int64_t ldc1) {
+    if (!L || !W || !C0 || !C1 || n1 <= 0 || n2 <= 0 || ldl < n2 || ldw < n1 || ldc0 < n2 || ldc1 < n2) return GPX_ERR_ARG;
+    return gpx_gemm_pair(0, n2, n2, n1, -1.0, L, ldl, L, ldl, 1.0, C0, ldc0, GEMM_LOWER, n2, n1, n1, 1.0, L, ldl, W, ldw, 0.0, C1,
+                         ldc1, GEMM_KLO_N);
+}
+
 int gpx_dscal_stream(double* buf, int64_t count, double factor, void* hip_stream) {
     if (!buf || count < 0) return GPX_ERR_ARG;
     return gpx_vec_shift(static_cast<hipStream_t>(hip_stream), count, buf, 0.0, factor, buf);

@@ -277,3 +277,30 @@ def test_splitk_gram_with_row_panelled_operands(n, m, scale):
     assert np.max(np.abs(got - want)[low]) <= 1e-12 * np.max(np.abs(want))
     plain = gpx.dgemm(K, K, a_kc=True, b_kc=True, flags=gpx.GEMM_LOWER, splitk_work=work, kscale=g if scale else None)
     assert np.max(np.abs(got - plain)[low]) <= 1e-12 * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("n2,n1", [(128, 128), (200, 136), (512, 512), (1024, 1024), (2048, 2048), (4096, 2048)])
+def test_paired_products_of_a_recursion_node(n2, n1):
+    """gpx_gemm_pair (one launch for A22 -= L21 L21^T and T = L21 W11 below the 128-tile sizes, two launches above and
+    beyond GPX_PAIR_MAX_GRID workgroups) against NumPy and, bit for bit, against the two separate products."""
+    import ctypes as C
+    gpx = _lib()
+    L = gpx.lib
+    _vp, _i64 = C.c_void_p, C.c_int64
+    L.gpx_dgemm_pair_node.argtypes = [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64]
+    rng = np.random.default_rng(n2 + n1)
+    L21 = rng.normal(size=(n2, n1))
+    W11 = np.tril(rng.normal(size=(n1, n1)))
+    A22 = rng.normal(size=(n2, n2))
+    dL, dW = gpx.DeviceBuffer.from_numpy(L21.T.copy()), gpx.DeviceBuffer.from_numpy(W11.T.copy())   # column-major
+    dC0, dC1 = gpx.DeviceBuffer.from_numpy(A22.T.copy()), gpx.DeviceBuffer(n2 * n1)
+    dC1.zero()
+    gpx.check(L.gpx_dgemm_pair_node(n2, n1, dL.ptr, n2, dW.ptr, n1, dC0.ptr, n2, dC1.ptr, n2), "pair")
+    got0, got1 = dC0.to_numpy().reshape(n2, n2).T, dC1.to_numpy().reshape(n1, n2).T
+    want0, want1 = A22 - L21 @ L21.T, L21 @ W11
+    low = np.tril(np.ones((n2, n2), bool))
+    assert np.max(np.abs(got0 - want0)[low]) <= 1e-12 * np.max(np.abs(want0))
+    assert np.max(np.abs(got1 - want1)) <= 1e-12 * np.max(np.abs(want1))
+    sep0 = gpx.dgemm(L21, L21, C_in=A22, alpha=-1.0, beta=1.0, flags=gpx.GEMM_LOWER)
+    sep1 = gpx.dgemm(L21, W11.T.copy(), b_kc=True, flags=gpx.GEMM_KLO_N)
+    assert np.array_equal(got0[low], sep0[low]) and np.array_equal(got1, sep1)
