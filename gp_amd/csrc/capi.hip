@@ -40,6 +40,8 @@ int gpx_ctx_create(int device, gpx_ctx** out) {
         c->panels = !(e && e[0] == '1');
         e = getenv("GPX_FITC_NO_WHITEN");
         c->fitc_whiten = !(e && e[0] == '1');
+        e = getenv("GPX_SPARSE_SERIAL_MM");
+        c->sparse_side_mm = !(e && e[0] == '1');
     }
     // every failing step releases what the steps before it created (gpx_ctx_destroy copes with a half-built context)
     auto build = [&]() -> int {

@@ -58,6 +58,12 @@ struct gpx_ctx {
     bool panels = true;          // GPX_NO_PANELS=1: the n x m matrices of the sparse models plain column-major (A/B)
     bool fitc_whiten = true;     // GPX_FITC_NO_WHITEN=1: the reference's A = sn2 Kuu + Kux G^-1 Kxu instead of M = sn2 I + V^T G^-1 V (A/B)
     bool mfma_pairwise = true;   // GPX_NO_MFMA_PAIRWISE=1 keeps the vector-unit kernels (A/B runs, fallback tests)
+    // GPX_SPARSE_SERIAL_MM=1 (A/B): the m x m products behind the two factor chains (Kuu^-1, W_M W_u, A^-1) on the main
+    // stream in phase 3 and the W buffers zero-filled per evaluation, as before round 3's last change
+    bool sparse_side_mm = true;
+    // Winv_u / Winv_A: the (buffer, m) whose upper triangle is known to be zero (gpx_potrf_inv writes the lower one only)
+    const double* winv_clean_p[2] = {nullptr, nullptr};
+    long winv_clean_m[2] = {0, 0};
     // all-reduce hook for row-sharded FITC/VFE
     gpx_allreduce_fn allreduce = nullptr;                 // host-synchronous flavour
     gpx_allreduce_stream_fn allreduce_stream = nullptr;   // stream-ordered flavour (preferred)

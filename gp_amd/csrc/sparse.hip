@@ -319,6 +319,15 @@ struct Sparse {
         else HIP_TRY(hipStreamSynchronize(consumer));
         return c->allreduce(buf, count, c->allreduce_user) ? GPX_ERR_STATE : GPX_OK;
     }
+    // gpx_potrf_inv writes the lower triangle of W only and the products that read W rely on zeros above it: the
+    // zero-fill is needed once per (buffer, m), not per evaluation (39 us each at m = 1024, at the head of both chains)
+    int clean_winv(int slot, DevBuf& W, hipStream_t s_) {
+        if (c->sparse_side_mm && c->winv_clean_p[slot] == W.p && c->winv_clean_m[slot] == m) return GPX_OK;
+        HIP_TRY(hipMemsetAsync(W.p, 0, (size_t)ldm * m * sizeof(double), s_));
+        c->winv_clean_p[slot] = W.p;
+        c->winv_clean_m[slot] = m;
+        return GPX_OK;
+    }
     // full symmetric inverse of a factored m x m matrix: Winv = L^-1, Inv = Winv^T Winv
     int inverse(const double* L, const double* Wd, double* Winv, double* Inv, bool need_winv_only = false) {
         int rc;
@@ -362,9 +371,11 @@ struct Sparse {
     // HBM-bound GEMV F = Kux r (whose workgroups hold no LDS; the Kxu build's do, and the 150 KB base block of the chain
     // found no CU until the 25 ms build had ended: profiles/r02d_vfe) and phase 2 follows it on the side stream anyway.
     // The chain then takes its own scratch (c->Tc): c->T holds the split-K slabs of the Gram product meanwhile.
-    int kernels(double kuu_jitter, bool fused_inverse = false, bool overlap = false, bool defer_join = false) {
+    int kernels(double kuu_jitter, bool fused_inverse = false, bool overlap = false, bool defer_join = false,
+                bool kuu_inv_behind = false) {
         int rc;
-        if ((rc = gpx_scale_inputs(st, c->X.p, n, d, c->dpad, h.sc, c->Xt.p, c->ldx))) return rc;
+        // the inducing points first: the chain needs nothing of X, and scaling X takes 0.2 ms at n = 2^20 - a head start
+        // for the chain before the Kxu build fills every CU (its small launches then find no room until the build ends)
         if ((rc = gpx_scale_inputs(st, c->U.p, m, d, c->dpad, h.sc, c->Ut.p, c->ldu))) return rc;
         if ((rc = gpx_cov_build(st, c->Ut.p, c->ldu, m, c->Ut.p, c->ldu, m, c->dpad, h.sf2, c->Kuu.p, ldm, 1, kuu_jitter)))
             return rc;
@@ -377,10 +388,17 @@ struct Sparse {
                 sf = c->st2;
                 HIP_TRY(hipEventRecord(c->ev[0], st));
                 HIP_TRY(hipStreamWaitEvent(sf, c->ev[0], 0));
-                if ((rc = build_kxu())) return rc;
-                if ((rc = gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p))) return rc;
+                if ((rc = gpx_scale_inputs(st, c->X.p, n, d, c->dpad, h.sc, c->Xt.p, c->ldx))) return rc;
+                if (defer_join) {   // VFE: nothing waits for the chain in phase 1, the 25 ms build goes first
+                    if ((rc = build_kxu())) return rc;
+                    if ((rc = gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p))) return rc;
+                }
+                // FITC: V needs W_u right after the build, and a chain launched beside the build stands still until the
+                // build has drained (its small launches find no free registers on any CU: 0.45 ms of waiting at n = 2^20,
+                // 0.54 ms at the 8-GPU shard size) - the chain is queued FIRST and runs while the host is still launching
+                // it; the build follows.
             }
-            HIP_TRY(hipMemsetAsync(c->Winv_u.p, 0, (size_t)ldm * m * sizeof(double), sf));
+            if ((rc = clean_winv(0, c->Winv_u, sf))) return rc;
             double* tscr = c->T.p;
             if (overlap && defer_join) {
                 if ((rc = c->Tc.ensure(gpx_trtri_scratch(m)))) return rc;
@@ -390,13 +408,25 @@ struct Sparse {
             if (overlap) {
                 if (!defer_join) {
                     HIP_TRY(hipEventRecord(c->ev[1], sf));
+                    if ((rc = build_kxu())) return rc;
+                    if ((rc = gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p))) return rc;
                     HIP_TRY(hipStreamWaitEvent(st, c->ev[1], 0));
+                }
+                if (kuu_inv_behind) {
+                    // Kuu^-1 = W_u^T W_u (FITC gradient) right behind the chain on the side stream, beside the n m^2
+                    // products of phase 1, instead of on the main stream at the head of phase 3
+                    const hipStream_t keep = st;
+                    st = sf;
+                    rc = gram(c->Winv_u.p, c->Kuu_inv.p);
+                    st = keep;
+                    if (rc) return rc;
                 }
                 return GPX_OK;
             }
         } else if ((rc = gpx_potrf(st, m, c->Lu.p, ldm, c->Wd_u.p, c->info))) {
             return rc;
         }
+        if ((rc = gpx_scale_inputs(st, c->X.p, n, d, c->dpad, h.sc, c->Xt.p, c->ldx))) return rc;
         if ((rc = build_kxu())) return rc;
         return gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p);
     }
@@ -459,7 +489,8 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     const bool wh = fitc && c->fitc_whiten;
     const double* gram_op = wh ? c->V.p : c->Kxu.p;
     // ---- phase 1 ------------------------------------------------------------------------------
-    if ((rc = s.kernels(jitter, true, true, !fitc))) return rc;  // Lu diag + Winv_u = Lu^-1
+    const bool side_mm = c->sparse_side_mm && calc_grad;
+    if ((rc = s.kernels(jitter, true, true, !fitc, fitc && side_mm))) return rc;  // Lu diag + Winv_u = Lu^-1
     HIP_TRY(hipMemsetAsync(redT, 0, 16 * sizeof(double), st));
     if (mp > m) HIP_TRY(hipMemsetAsync(redF + m, 0, (mp - m) * sizeof(double), st));   // the padding travels with all-reduce #1
     if (fitc) {
@@ -502,12 +533,13 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     HIP_TRY(hipStreamWaitEvent(st, c->ev[0], 0));
     if (wh)   // M = sn2 I + V^T Gamma^-1 V
         hipLaunchKernelGGL(mm_combine_lower_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, 0.0, c->Kuu.p, ldm, 1.0, red, m,
-                           h.sn2, c->Am.p, ldm);
+                           h.sn2, c->LA.p, ldm);
     else
         hipLaunchKernelGGL(mm_combine_lower_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, h.sn2, c->Kuu.p, ldm, 1.0, red, m,
-                           0.0, c->Am.p, ldm);
-    HIP_TRY(hipMemcpyAsync(c->LA.p, c->Am.p, (size_t)ldm * m * sizeof(double), hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemsetAsync(c->Winv_A.p, 0, (size_t)ldm * m * sizeof(double), st));
+                           0.0, c->LA.p, ldm);
+    // (straight into the buffer the factorisation works in: the 8 MB copy from a separate A took 146 us of this
+    // latency-bound path beside the B product at the 8-GPU shard size)
+    if ((rc = s.clean_winv(1, c->Winv_A, st))) return rc;
     if ((rc = gpx_potrf_inv(st, m, c->LA.p, ldm, c->Winv_A.p, ldm, c->T.p, c->info + 1))) return rc;
     // z = W_A F (whitened: W_M F_v);  F^T A^-1 F = z^T z;  a = A^-1 F = W_A^T z (whitened: W_u^T W_M^T z)
     if ((rc = gpx_gemv_n(st, m, m, 1.0, c->Winv_A.p, ldm, redF, 0.0, c->vm[1].p, 1))) return rc;
@@ -531,8 +563,28 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     HIP_TRY(hipMemcpyAsync(hs + 8, redT, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hs + 16, c->info, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     tr.mark("phase 2 enqueued");
-    HIP_TRY(hipStreamSynchronize(st));  // the side stream is drained: phase 3 needs no event
-    tr.mark("phase 2 done on the device (side stream drained)");
+    // A^-1 for the gradient: W_A = W_M W_u (whitened; lower x lower: B(n,k) = W_u[k + n ldm] is zero for k < n), A^-1 = W_A^T W_A.
+    auto a_inverse = [&]() -> int {
+        if (wh) {
+            int r2 = gpx_gemm(s.st, 0, 1, m, m, m, 1.0, c->Winv_A.p, ldm, c->Winv_u.p, ldm, 0.0, c->Am.p, ldm, GEMM_KLO_N);
+            return r2 ? r2 : s.gram(c->Am.p, c->A_inv.p);
+        }
+        return s.gram(c->Winv_A.p, c->A_inv.p);
+    };
+    if (side_mm) {
+        // The host only needs the scalars: it waits for an event behind their copies, and the m x m products of A^-1 go on
+        // behind that event on the side stream - they run while the host enqueues phase 3 and the main stream finishes B,
+        // and the main stream waits for them through a second event (they were ~0.3 ms at the head of phase 3, exposed at
+        // the 8-GPU shard size).  If the factorisation failed they work on garbage and nobody reads the result.
+        HIP_TRY(hipEventRecord(c->ev[1], st));
+        if ((rc = a_inverse())) return rc;
+        HIP_TRY(hipEventRecord(c->ev[0], st));
+        HIP_TRY(hipEventSynchronize(c->ev[1]));
+        tr.mark("phase 2 scalars on the host");
+    } else {
+        HIP_TRY(hipStreamSynchronize(st));  // the side stream is drained: phase 3 needs no event
+        tr.mark("phase 2 done on the device (side stream drained)");
+    }
     st = st_main;
     s.st = st;
     int info[2];
@@ -558,19 +610,15 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     }
     if (info[0] != 0 || info[1] != 0 || !std::isfinite(v)) {
         HIP_TRY(hipStreamSynchronize(st));  // B may still be running
+        if (side_mm) HIP_TRY(hipStreamSynchronize(c->st2));
         return GPX_OK;                      // NLL = INF, g = 0
     }
     *nll = v;
     if (!calc_grad) return GPX_OK;
 
     // ---- phase 3 ------------------------------------------------------------------------------
-    if (wh) {
-        // W_A = W_M W_u (lower x lower; B(n,k) = W_u[k + n ldm] is zero for k < n), A^-1 = W_A^T W_A
-        if ((rc = gpx_gemm(st, 0, 1, m, m, m, 1.0, c->Winv_A.p, ldm, c->Winv_u.p, ldm, 0.0, c->Am.p, ldm, GEMM_KLO_N))) return rc;
-        if ((rc = s.gram(c->Am.p, c->A_inv.p))) return rc;
-    } else if ((rc = s.gram(c->Winv_A.p, c->A_inv.p))) {
-        return rc;
-    }
+    if (side_mm) HIP_TRY(hipStreamWaitEvent(st, c->ev[0], 0));   // A^-1 (and Kuu^-1 before it) from the side stream
+    else if ((rc = a_inverse())) return rc;
     TraceArgs ta = {};
     ta.Xt1 = c->Xt.p; ta.ld1 = c->ldx; ta.p = n;
     ta.Xt2 = c->Ut.p; ta.ld2 = c->ldu; ta.q = m;
@@ -579,7 +627,7 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
     ta.v = a_vec;
     HIP_TRY(hipMemsetAsync(redT, 0, (GPX_MAX_DIM + 32) * sizeof(double), st));
     if (fitc) {
-        if ((rc = s.gram(c->Winv_u.p, c->Kuu_inv.p))) return rc;
+        if (!side_mm && (rc = s.gram(c->Winv_u.p, c->Kuu_inv.p))) return rc;
         // C = Gamma^-1 Kxu A^-1 (FITC.cpp:262) and B = Kxu Kuu^-1 = V Lu^-1 (FITC.cpp:214)
         double* Cm = c->Cm.p;  // Cu = Kxu A^-1; C = diag(1/Gamma) Cu enters through per-row coefficients
         GemmRowdot rd = {};   // rowsum(Cu o Kxu) and Kxu a leave the GEMM with Cu

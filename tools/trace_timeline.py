@@ -35,7 +35,7 @@ for r in sel:
     a[1] += e - s
     a[2] += max(gap, 0)
     if full:
-        print(f"{(s - t0) / 1e3:10.1f} us  +{(e - s) / 1e3:9.1f} us  gap {gap / 1e3:8.1f} us  {name}")
+        print(f"{(s - t0) / 1e3:10.1f} us  +{(e - s) / 1e3:9.1f} us  gap {gap / 1e3:8.1f} us  s{r.get('Stream_Id', '?'):>2s}  {name}")
     prev_end = max(prev_end, e)
 wall = prev_end - t0
 print(f"evaluation {which}: {len(sel)} dispatches, wall {wall / 1e6:.3f} ms, busy {busy / 1e6:.3f} ms, idle {(wall - busy) / 1e6:.3f} ms")
