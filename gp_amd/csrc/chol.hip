@@ -8,6 +8,7 @@
 // one-workgroup kernel, and triangular solves against them are products with those inverses.
 #include "gpx_internal.h"
 #include "kernels.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -574,13 +575,14 @@ __global__ void copy_base_blocks_kernel(const double* __restrict__ Wd, long n, d
     }
 }
 
-__global__ void logdiag_sum_kernel(const double* __restrict__ A, long lda, long n, double* __restrict__ out) {
-    __shared__ double red[256];
+__global__ void __launch_bounds__(1024) logdiag_sum_kernel(const double* __restrict__ A, long lda, long n, double* __restrict__ out) {
+    // one workgroup (fixed summation order); 1024 threads: every diagonal entry is a cache line of its own
+    __shared__ double red[1024];
     double s = 0.0;
-    for (long i = threadIdx.x; i < n; i += 256) s += log(A[i + i * lda]);
+    for (long i = threadIdx.x; i < n; i += 1024) s += log(A[i + i * lda]);
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
@@ -712,8 +714,7 @@ int gpx_potrf(hipStream_t st, long n, double* A, long lda, double* Wd, int* info
     return GPX_OK;
 }
 
-int gpx_potrf_inv(hipStream_t st, long n, double* A, long lda, double* W, long ldw, double* T, int* info) {
-    if (n <= 0) return GPX_OK;
+static void chol_env_once() {
     static const bool init = [] {
         const char* e = getenv("GPX_BASE64");
         g_base64 = e && e[0] == '1';
@@ -722,11 +723,23 @@ int gpx_potrf_inv(hipStream_t st, long n, double* A, long lda, double* W, long l
         return true;
     }();
     (void)init;
+}
+
+int gpx_potrf_inv(hipStream_t st, long n, double* A, long lda, double* W, long ldw, double* T, int* info) {
+    if (n <= 0) return GPX_OK;
+    chol_env_once();
     const int rc = potrf_inv_rec(st, n, A, lda, W, ldw, T, info);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return GPX_OK;
 }
+
+// (Measured and dropped, round 3: Out11 = W11^T W11 of the final W^T W formed on the side stream BESIDE the recursion on A22
+// at n = 8192, as block products of at most 128 workgroups so that half of the CUs stay empty for the chain, the rest
+// of W^T W as three products afterwards.  The base blocks keep their 36 us, but the chain's small products - bound by
+// the latency of their dependent global loads - run 2-3 times slower while the side product streams through memory
+// (128-row level 5.2 -> ~14 us), and the three remaining 4096-row pieces take as long as the single 8192-row launch
+// they replace (2.75 ms: 60 / 69 / 38 TFLOP/s against 66.6): 12.6 -> 14.0 ms, same box.)
 
 long gpx_trtri_scratch(long n) {   // covers gpx_trtri (64-row base) and gpx_potrf_inv (128-row base)
     if (n <= NB) return 16;
@@ -780,7 +793,7 @@ int gpx_trsv(hipStream_t st, long n, const double* L, long ldl, const double* Wd
 }
 
 int gpx_logdiag_sum(hipStream_t st, long n, const double* A, long lda, double* out) {
-    hipLaunchKernelGGL(logdiag_sum_kernel, dim3(1), dim3(256), 0, st, A, lda, n, out);
+    hipLaunchKernelGGL(logdiag_sum_kernel, dim3(1), dim3(1024), 0, st, A, lda, n, out);
     HIP_TRY(hipGetLastError());
     return GPX_OK;
 }
