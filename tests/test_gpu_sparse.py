@@ -269,3 +269,39 @@ def test_row_panels_and_whitening_switches_agree(gpx, model, monkeypatch):
         print(f"\n[{model} {env}] rel diff NLL {e[0]:.2e} gradient {e[1]:.2e} mean {e[2]:.2e} variance {e[3]:.2e}")
         # two fp64 evaluation orders of the same _setK state: jitter 1e-6, inducing points that are training rows (measured 9e-10 / 4e-10)
         assert e[0] <= 1e-9 and e[1] <= 1e-7 and e[2] <= 1e-8 and e[3] <= 1e-8
+
+
+@pytest.mark.parametrize("model", ["fitc", "vfe"])
+def test_stream_order_switch_and_changing_inducing_sets(gpx, model, monkeypatch):
+    """The m x m products behind the factor chains run on the side stream behind events and the W buffers are zero-filled
+    once per (buffer, m) (sparse.hip): (i) the same context evaluated with inducing sets of different sizes in turn - a
+    larger one, a smaller one (the buffers keep their capacity: stale entries of the old lower triangle lie above the new
+    diagonal and must be cleared), the first one again - gives, every time, bit for bit what a fresh context gives; (ii) a
+    context created with GPX_SPARSE_SERIAL_MM=1 (everything on the main stream, zero-fill per evaluation) gives the same bits."""
+    M = gpx.MODEL_FITC if model == "fitc" else gpx.MODEL_VFE
+    n, d = 1500, 7
+    X, y, hyp, _, U_all = problem(0, n, d, 400)
+
+    def fresh(U):
+        c = gpx.Context()
+        c.set_data(X, y)
+        c.set_inducing(U)
+        out = c.nll_grad(M, 0, hyp, jitter=1e-6)
+        c.close()
+        return out
+
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    for m in (260, 400, 130, 260, 129):
+        U = U_all[:m]
+        ctx.set_inducing(U)
+        nll, g = ctx.nll_grad(M, 0, hyp, jitter=1e-6)
+        nll2, g2 = ctx.nll_grad(M, 0, hyp, jitter=1e-6)   # and again on buffers that are known to be clean
+        nll_f, g_f = fresh(U)
+        assert nll == nll_f == nll2 and np.array_equal(g, g_f) and np.array_equal(g, g2), (m, nll, nll_f, nll2)
+    ctx.close()
+    monkeypatch.setenv("GPX_SPARSE_SERIAL_MM", "1")
+    nll_s, g_s = fresh(U_all[:260])
+    monkeypatch.delenv("GPX_SPARSE_SERIAL_MM")
+    nll_p, g_p = fresh(U_all[:260])
+    assert nll_s == nll_p and np.array_equal(g_s, g_p)
