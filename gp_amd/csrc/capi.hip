@@ -79,7 +79,7 @@ int gpx_ctx_destroy(gpx_ctx* c) {
                       &c->Am, &c->LA, &c->Winv_u, &c->Winv_A, &c->Kuu_inv, &c->A_inv, &c->Wuu,
                       &c->Wd_u, &c->Wd_A, &c->red, &c->pred_K, &c->pred_xs, &c->pred_xst, &c->pred_out,
                       &c->pred_tmp, &c->pred_K2, &c->pred_g, &c->pLu, &c->pLA, &c->pWd_u, &c->pWd_A, &c->palpha, &c->pUt,
-                      &c->Xa, &c->Ua, &c->UaT, &c->cen, &c->cpart, &c->spart, &c->cvec, &c->rowp1, &c->rowp2};
+                      &c->Xa, &c->Ua, &c->UaT, &c->cen, &c->cpart, &c->spart, &c->cvec, &c->rowp1, &c->rowp2, &c->gemv_ws};
     for (DevBuf* b : bufs) b->release();
     for (auto& b : c->vn) b.release();
     for (auto& b : c->vm) b.release();

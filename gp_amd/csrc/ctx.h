@@ -52,6 +52,7 @@ struct gpx_ctx {
     // sparse workspaces (sparse.hip)
     DevBuf Kxu, V, Bm, Cm, Kuu, Lu, Am, LA, Winv_u, Winv_A, Kuu_inv, A_inv, Wuu, Wd_u, Wd_A;
     DevBuf vn[8], vm[8], red;
+    DevBuf gemv_ws;   // partial sums of the row-split transposed GEMV (F = Kux r / F_v = V^T Gamma^-1 r)
     // matrix-core pairwise path (pairwise_mfma.hip): centred, augmented operands and its partial sums
     DevBuf Xa, Ua, UaT, cen, cpart, spart, cvec;
     DevBuf rowp1, rowp2;  // FITC: per-64-column partial row sums written by the GEMM row-dot epilogue [2 ceil(m/128)][ldn]

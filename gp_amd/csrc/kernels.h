@@ -93,3 +93,7 @@ int gpx_gemv_n(hipStream_t st, long M, long K, double alpha, const double* A, lo
 // pan / pst: the M rows of A in row panels (GemmPanels in gpx_internal.h; 0 = plain; not with tri)
 int gpx_gemv_t(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
                double beta, double* y, int tri = 0, long pan = 0, long pst = 0);
+// tall matrices with few columns: the rows cut into parts that run side by side, parts summed in a fixed order (vecops.hip)
+long gpx_gemv_t_split_ws(long K);
+int gpx_gemv_t_split(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
+                     double beta, double* y, long pan, long pst, double* ws);

@@ -291,7 +291,7 @@ struct Sparse {
         if ((rc = c->T.ensure(tcap))) return rc;
         for (int i = 0; i < 8; ++i)
             if ((rc = c->vn[i].ensure(n)) || (rc = c->vm[i].ensure(m + 80))) return rc;  // + 64: direct-to-LDS loads read whole 32-entry tiles
-        if ((rc = c->red.ensure(m * m + m + GPX_MAX_DIM + 96))) return rc;
+        if ((rc = c->red.ensure(m * m + m + GPX_MAX_DIM + 96)) || (rc = c->gemv_ws.ensure(gpx_gemv_t_split_ws(m)))) return rc;
         if ((rc = c->r.ensure(n))) return rc;
         if ((rc = c->pred_tmp.ensure((long)PW * (nblk(n) > nblk(m * m) ? nblk(n) : nblk(m * m)) + 64))) return rc;
         return GPX_OK;
@@ -500,11 +500,11 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         // (this HBM-bound GEMV on the side stream, beside the matrix-pipe-bound Gram product below, was measured: the Gram
         // product loses more than the GEMV's 1.65 ms, 113.4 -> 114.9 ms per evaluation)
         // whitened form (default): F_v = V^T Gamma^-1 r = Lu^-1 F;  else F = Kux Gamma^-1 r (FITC.cpp:218)
-        if ((rc = gpx_gemv_t(st, n, m, 1.0, gram_op, ldk, p, 0.0, redF, 0, s.pan, s.pst))) return rc;
+        if ((rc = gpx_gemv_t_split(st, n, m, 1.0, gram_op, ldk, p, 0.0, redF, s.pan, s.pst, c->gemv_ws.p))) return rc;
     } else {
         hipLaunchKernelGGL(vfe_rstats_kernel, dim3(nblk(n)), dim3(256), 0, st, n, c->r.p, s.part());
         s.finish_partials(n, redT, 3);  // r^T r, -, n_local
-        if ((rc = gpx_gemv_t(st, n, m, 1.0, c->Kxu.p, ldk, c->r.p, 0.0, redF, 0, s.pan, s.pst))) return rc;  // F = Kux r
+        if ((rc = gpx_gemv_t_split(st, n, m, 1.0, c->Kxu.p, ldk, c->r.p, 0.0, redF, s.pan, s.pst, c->gemv_ws.p))) return rc;  // F = Kux r
     }
     // S = Kux [Gamma^-1] Kxu, lower tiles, split-K over the training rows (FITC.cpp:217, VFE.cpp:173)
     // (F = Kux [Gamma^-1] r as an operand dot of THIS product - from the A fragments of its first tile column, partial sums

@@ -1,6 +1,8 @@
 // vecops.hip — memory-bound vector / matrix-vector helpers (gfx950).
 #include "gpx_internal.h"
 #include "kernels.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -63,17 +65,28 @@ __global__ __launch_bounds__(64 * GEMV_NW) void gemv_n_kernel(long M, long K, do
 
 // y[j] = beta*y[j] + alpha * sum_i A[i + j*lda] x[i]; one wave per column.  pan > 0: the M rows live in row panels of pan
 // rows (element (i, j) at (i / pan) * pst + i % pan + j * lda): the column is walked panel by panel.
+// nsplit > 1 (blockIdx.y = part): the rows are cut into nsplit parts (whole panels, or multiples of 512 rows) and every
+// part writes its sum to ws[part * K + j]; gemv_t_finish_kernel adds the parts in a fixed order.  One wave per column is
+// 1024 waves for the n x 1024 matrices of FITC - four per CU: the 1 GB shard of the 8-GPU case streamed at 3.5 TB/s.
 __global__ __launch_bounds__(256) void gemv_t_kernel(long M, long K, double alpha, const double* __restrict__ A,
                                                      long lda, const double* __restrict__ x, double beta,
-                                                     double* __restrict__ y, int tri, long pan, long pst) {
+                                                     double* __restrict__ y, int tri, long pan, long pst, int nsplit,
+                                                     double* __restrict__ ws) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long j = (long)blockIdx.x * 4 + w;
     if (j >= K) return;
     double s0 = 0.0, s1 = 0.0;
     const long step = pan ? pan : M;
-    for (long r0 = 0; r0 < M; r0 += step) {
+    long rb = 0, re = M;
+    if (nsplit > 1) {
+        const long unit = pan ? pan : 512, nu = (M + unit - 1) / unit;
+        rb = (nu * blockIdx.y / nsplit) * unit;
+        re = (nu * (blockIdx.y + 1) / nsplit) * unit;
+        if (re > M) re = M;
+    }
+    for (long r0 = rb; r0 < re; r0 += step) {
         const double* a = A + j * lda + (pan ? (r0 / pan) * pst - r0 : 0);   // a[i] = element (i, j) for r0 <= i < r1
-        const long r1 = r0 + step < M ? r0 + step : M;
+        const long r1 = r0 + step < re ? r0 + step : re;
         long i0 = tri ? j : r0;  // lower triangular: rows >= column
         if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(x)) & 15) == 0) {
             // long columns (the n x m products of the sparse models have only m of them): 16-B loads, eight
@@ -108,7 +121,18 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(long M, long K, double alph
     }
     double s = s0 + s1;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (l == 0) y[j] = beta == 0.0 ? alpha * s : beta * y[j] + alpha * s;
+    if (l == 0) {
+        if (nsplit > 1) ws[(long)blockIdx.y * K + j] = s;
+        else y[j] = beta == 0.0 ? alpha * s : beta * y[j] + alpha * s;
+    }
+}
+__global__ __launch_bounds__(256) void gemv_t_finish_kernel(long K, int nsplit, const double* __restrict__ ws, double alpha,
+                                                            double beta, double* __restrict__ y) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= K) return;
+    double s = 0.0;
+    for (int q = 0; q < nsplit; ++q) s += ws[(long)q * K + j];
+    y[j] = beta == 0.0 ? alpha * s : beta * y[j] + alpha * s;
 }
 
 }  // namespace
@@ -126,6 +150,24 @@ int gpx_gemv_t(hipStream_t st, long M, long K, double alpha, const double* A, lo
     if (K <= 0) return GPX_OK;
     if (pan && (tri || pan % 2 || pst % 2)) return GPX_ERR_ARG;
     hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)((K + 3) / 4)), dim3(256), 0, st, M, K, alpha, A, lda, x, beta,
-                       y, tri, pan, pst);
+                       y, tri, pan, pst, 1, (double*)nullptr);
+    return GPX_OK;
+}
+
+// The same product with the rows cut into parts that run side by side (tall matrices with few columns); ws holds
+// gpx_gemv_t_split_ws(K) doubles.  Deterministic: fixed parts, fixed order of the final sum.
+long gpx_gemv_t_split_ws(long K) { return 8 * K; }
+int gpx_gemv_t_split(hipStream_t st, long M, long K, double alpha, const double* A, long lda, const double* x,
+                     double beta, double* y, long pan, long pst, double* ws) {
+    if (K <= 0) return GPX_OK;
+    if (pan && (pan % 2 || pst % 2)) return GPX_ERR_ARG;
+    // enough waves for ~16 per CU, parts of at least 8192 rows
+    static const int forced = [] { const char* e = getenv("GPX_GEMV_SPLIT"); return e ? atoi(e) : 0; }();
+    int nsplit = forced > 0 ? forced : (int)std::min<long>(8, std::max<long>(1, std::min<long>(4096 / std::max<long>(K, 1), M / 8192)));
+    if (nsplit > 8) nsplit = 8;
+    if (nsplit <= 1 || !ws) return gpx_gemv_t(st, M, K, alpha, A, lda, x, beta, y, 0, pan, pst);
+    hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)((K + 3) / 4), (unsigned)nsplit), dim3(256), 0, st, M, K, alpha, A, lda, x,
+                       beta, y, 0, pan, pst, nsplit, ws);
+    hipLaunchKernelGGL(gemv_t_finish_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, K, nsplit, ws, alpha, beta, y);
     return GPX_OK;
 }
