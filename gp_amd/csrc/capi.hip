@@ -42,6 +42,8 @@ int gpx_ctx_create(int device, gpx_ctx** out) {
         c->fitc_whiten = !(e && e[0] == '1');
         e = getenv("GPX_SPARSE_SERIAL_MM");
         c->sparse_side_mm = !(e && e[0] == '1');
+        e = getenv("GPX_FITC_SINGLE_AR2");
+        c->fitc_split_ar2 = !(e && e[0] == '1');
     }
     // every failing step releases what the steps before it created (gpx_ctx_destroy copes with a half-built context)
     auto build = [&]() -> int {

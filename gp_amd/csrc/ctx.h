@@ -62,6 +62,7 @@ struct gpx_ctx {
     // GPX_SPARSE_SERIAL_MM=1 (A/B): the m x m products behind the two factor chains (Kuu^-1, W_M W_u, A^-1) on the main
     // stream in phase 3 and the W buffers zero-filled per evaluation, as before round 3's last change
     bool sparse_side_mm = true;
+    bool fitc_split_ar2 = true;   // GPX_FITC_SINGLE_AR2=1: one all-reduce #2 behind the trace (A/B); default: m x m part beside the trace
     // Winv_u / Winv_A: the (buffer, m) whose upper triangle is known to be zero (gpx_potrf_inv writes the lower one only)
     const double* winv_clean_p[2] = {nullptr, nullptr};
     long winv_clean_m[2] = {0, 0};

@@ -640,17 +640,32 @@ int gpx_sparse_nll_grad(gpx_ctx* c, int model, int cov, const double* hyp, int c
         hipLaunchKernelGGL(fitc_rowstats_kernel, dim3(nblk(n)), dim3(256), 0, st, n, (int)s.nparts(), c->rowp1.p, c->rowp2.p, ldn,
                            g, p, h.sn2, c2coef, ucoef, wv, s.part());
         s.finish_partials(n, redT + GPX_MAX_DIM + 8, 4);  // sum(g-c1), sum pq^2, sum pq, sum w
+        // B^T diag(w) B: w (signed) is the K-dimension scale of the lower-tile split-K product.  It goes BEFORE the trace:
+        // with a stream-ordered collective (RCCL, stream hook) the m x m part of all-reduce #2 then runs on the side stream
+        // beside the trace kernel, which needs nothing of it, and only the d + 6 trace sums are reduced behind the trace
+        // (#2b, a latency-sized collective) - the 8 MB collective is off the critical path.  The host-synchronous hook and
+        // GPX_FITC_SINGLE_AR2=1 keep ONE all-reduce #2 of [S | tail] behind the trace.
+        if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Bm.p, ldk, c->Bm.p, ldk, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
+                                  wv, &pnK)))
+            return rc;
+        const bool split_ar2 = c->fitc_split_ar2 && (c->rccl_comm || c->allreduce_stream);
+        if (split_ar2) {
+            HIP_TRY(hipEventRecord(c->ev[1], st));
+            if ((rc = s.allreduce(red, m * m, c->st2, c->ev[1]))) return rc;
+            HIP_TRY(hipEventRecord(c->ev[0], c->st2));
+        }
         // half of W_xu = C - (1/sn2) pq a^T - (1/sn2) diag(w) B, contracted with every dKxu at once
         ta.M1 = Cm; ta.ldm1 = ldk; ta.c1 = g;
         ta.M2 = c->Bm.p; ta.ldm2 = ldk; ta.c2 = c2coef;
         ta.u = ucoef;
         if ((rc = s.trace_xu(ta, redT))) return rc;
-        // B^T diag(w) B: w (signed) is the K-dimension scale of the lower-tile split-K product
-        if ((rc = gpx_gemm_splitk(st, 1, 1, m, m, n, 1.0, c->Bm.p, ldk, c->Bm.p, ldk, 0.0, red, m, GEMM_LOWER, c->T.p, c->T.cap,
-                                  wv, &pnK)))
-            return rc;
         tr.mark("phase 3 enqueued");
-        if ((rc = s.allreduce(red, m * m + GPX_MAX_DIM + 32, st))) return rc;
+        if (split_ar2) {
+            if ((rc = s.allreduce(redT, GPX_MAX_DIM + 32, st))) return rc;
+            HIP_TRY(hipStreamWaitEvent(st, c->ev[0], 0));   // the reduced m x m part
+        } else if ((rc = s.allreduce(red, m * m + GPX_MAX_DIM + 32, st))) {
+            return rc;
+        }
         tr.mark("all-reduce #2 returned to the host");
         hipLaunchKernelGGL(mm_symmetrize_kernel, dim3(nblk(m * m)), dim3(256), 0, st, m, red, m);
         // W_uu = sn2 A^-1 - Kuu^-1 + a a^T + B^T diag(w) B / sn2

@@ -163,8 +163,8 @@ public:
     // "Kuf.Kfu and diag corrections sharded by training rows ... RCCL all-reduce over xGMI").  THIS object holds the rows
     // shard_range(n, rank, world) of the training set (the caller constructs it from its shard), the inducing points and
     // the hypers are the same on every rank; nccl_comm is the caller's ncclComm_t (ncclCommInitRank, one rank per GPU).
-    // The library then issues the two sum-all-reduces of every evaluation (and the one of _setK) itself, on its own
-    // stream; NLL and gradient come out identical on every rank.  Call before the first evaluation or any time after.
+    // The library then issues the sum-all-reduces of every evaluation (VFE two; FITC three: the m x m part of the second
+    // one runs beside the trace kernel) and the one of _setK itself, on its own streams; NLL and gradient come out identical on every rank.  Call before the first evaluation or any time after.
     void set_communicator(void* nccl_comm, int rank, int world);
     int rank() const { return _rank; }
     int world() const { return _world; }

@@ -111,8 +111,11 @@ int gpx_set_allreduce(gpx_ctx* ctx, gpx_allreduce_fn fn, void* user);
  * sum-all-reduce on hip_stream (a hipStream_t of the library; buf is complete in that stream's
  * order, the consumers are queued behind the call on it) and return without waiting — e.g.
  * ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, comm, (hipStream_t)hip_stream).  The host then
- * never blocks inside an evaluation and the m x m chains stay queued ahead of the GPU.  Setting one
- * flavour clears the other. */
+ * never blocks inside an evaluation and the m x m chains stay queued ahead of the GPU.  The library
+ * has two streams and hands the hook whichever one the reduced values are consumed on (FITC: the
+ * m x m part of the second all-reduce goes on the side stream beside the gradient trace, the trace
+ * sums follow on the main stream: three calls per evaluation; VFE: two).  Setting one flavour
+ * clears the other. */
 typedef int (*gpx_allreduce_stream_fn)(double* buf, int64_t count, void* hip_stream, void* user);
 int gpx_set_allreduce_stream(gpx_ctx* ctx, gpx_allreduce_stream_fn fn, void* user);
 /* Native flavour (no reference counterpart; north star "RCCL all-reduce over xGMI of the m x m and m-vector partials"):

@@ -165,7 +165,13 @@ def test_sparse_stream_ordered_allreduce_hook(gpx, model):
         nll, g = ctx.nll_grad(M, 0, hyp, jitter=jit)
         assert abs(nll - nll_ref) <= 1e-9 * abs(nll_ref)
         assert rel(g, g_ref) <= 1e-7
-    assert len(calls) == 4 and all(s for _, s in calls)   # two collectives per evaluation, on a real stream
+    # collectives per evaluation, each on a real stream: #1 and #2 (VFE); FITC splits #2 into its m x m part (enqueued on
+    # the side stream before the trace kernel, beside which it runs) and the trace sums behind the trace
+    per_eval = 3 if model == "fitc" else 2
+    assert len(calls) == 2 * per_eval and all(s for _, s in calls)
+    if model == "fitc":
+        m = U.shape[0]
+        assert calls[1][0] == m * m and calls[2][0] < m * m and calls[1][1] != calls[2][1]   # sizes; two different streams
     ctx.prepare(M, 0, hyp, jitter=jit)
     mu, s2 = ctx.predict(Xs)
     assert rel(mu, mu_ref) <= 1e-9 and rel(s2, s2_ref) <= 1e-9
