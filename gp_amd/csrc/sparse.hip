@@ -365,8 +365,11 @@ struct Sparse {
         return gpx_pair_trace(st, ta, d, c->trace_ws.p, c->trace_ws.cap, out);
     }
     // inputs, Kuu (+jitter on its diagonal) factored into Lu, Kxu
-    // overlap: the Lu factor+inverse chain (one workgroup wide for most of its length) runs on the
-    // side stream while the main stream builds Kxu.
+    // overlap: the Lu factor+inverse chain (one workgroup wide for most of its length) runs on the side stream.
+    // FITC (!defer_join): V needs W_u right after the build, and a chain launched BESIDE the build stands still until the
+    // build has drained (the build's waves hold 500 of the 512 vector registers of every SIMD: the chain's small launches
+    // find no room on any CU - 0.45 ms of waiting at n = 2^20, 0.54 ms at the 8-GPU shard size), so the chain is queued
+    // FIRST and runs while the host is still launching it; the build follows on the main stream.
     // defer_join (VFE): nothing of phase 1 needs Lu, so the main stream does NOT wait for the chain: it runs beside the
     // HBM-bound GEMV F = Kux r (whose workgroups hold no LDS; the Kxu build's do, and the 150 KB base block of the chain
     // found no CU until the 25 ms build had ended: profiles/r02d_vfe) and phase 2 follows it on the side stream anyway.
@@ -384,19 +387,14 @@ struct Sparse {
         if (fused_inverse) {
             hipStream_t sf = st;
             if (overlap) {
-                // the chain below is host-launch-bound: queue the independent row-local work first
                 sf = c->st2;
                 HIP_TRY(hipEventRecord(c->ev[0], st));
                 HIP_TRY(hipStreamWaitEvent(sf, c->ev[0], 0));
                 if ((rc = gpx_scale_inputs(st, c->X.p, n, d, c->dpad, h.sc, c->Xt.p, c->ldx))) return rc;
-                if (defer_join) {   // VFE: nothing waits for the chain in phase 1, the 25 ms build goes first
+                if (defer_join) {   // VFE: the 25 ms build goes first (the chain's ~70 launches are host-bound)
                     if ((rc = build_kxu())) return rc;
                     if ((rc = gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p))) return rc;
                 }
-                // FITC: V needs W_u right after the build, and a chain launched beside the build stands still until the
-                // build has drained (its small launches find no free registers on any CU: 0.45 ms of waiting at n = 2^20,
-                // 0.54 ms at the 8-GPU shard size) - the chain is queued FIRST and runs while the host is still launching
-                // it; the build follows.
             }
             if ((rc = clean_winv(0, c->Winv_u, sf))) return rc;
             double* tscr = c->T.p;
