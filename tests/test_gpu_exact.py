@@ -88,6 +88,26 @@ def test_exact_nll_grad_vs_oracle(gpx, cov, n, d):
     ctx.close()
 
 
+@pytest.mark.parametrize("n,d", [(4230, 7)])
+def test_exact_nll_grad_vs_oracle_mid_size(gpx, n, d):
+    """The literal oracle (the same C restatement built with OpenMP, ~3 s on the box's cores) at a size whose recursion
+    reaches the 2048-row level: 128 x 128-tile products with triangular K ranges, the paired launches of a node, ragged
+    last blocks (n = 33 * 128 + 6) - the sizes between the n <= 1537 oracle tests and the property tests at 8192 / 65536."""
+    X, y, hyp, _ = synth.make_problem(5, n, d, 4)
+    hyp = hyp + np.concatenate([np.zeros(d), [0.05, 0.0, -0.02]])
+    ctx = gpx.Context()
+    ctx.set_data(X, y)
+    nll, g = ctx.nll_grad(gpx.MODEL_EXACT, 0, hyp)
+    nll_only = ctx.nll_grad(gpx.MODEL_EXACT, 0, hyp, calc_grad=False)
+    ctx.close()
+    nll_o, g_o = oracle.exact_nll_all_cores(0, X, y, hyp)
+    print(f"\n[exact n={n} d={d}] NLL rel {abs(nll - nll_o) / abs(nll_o):.2e}, gradient rel {rel(g, g_o):.2e}, "
+          f"NLL-only path rel {abs(nll_only - nll_o) / abs(nll_o):.2e}")
+    assert abs(nll - nll_o) <= 1e-9 * abs(nll_o)
+    assert rel(g, g_o) <= 1e-7
+    assert abs(nll_only - nll_o) <= 1e-9 * abs(nll_o)
+
+
 def test_exact_predict_grad_chunked_and_finite_difference(gpx):
     """more test points than one predict chunk, and the gradients against central differences"""
     n, d, t = 400, 4, 1100
