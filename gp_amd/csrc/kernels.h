@@ -48,7 +48,7 @@ int gpx_mfma_prepare(hipStream_t st, const double* Xt, long ldx, long n, const d
                      double* cen, double* Xa, double* Ua, double* UaT);
 // pan / pst: row-panel layout of out and of the weight matrices M1 / M2 (GemmPanels in gpx_internal.h; 0 = plain)
 int gpx_mfma_cov_build(hipStream_t st, const double* Xa, long n, const double* Ua, long m, int d, double sf2, double* out,
-                       long ldo, long pan = 0, long pst = 0);
+                       long ldo, long pan = 0, long pst = 0, int max_grid = 0);   // max_grid > 0: at most that many workgroups
 // weights from w (M1/c1, M2/c2, u/v); cpart: grid*ldua doubles, spart: grid*(n2+1), cvec: ldua
 int gpx_mfma_pair_trace(hipStream_t st, const double* Xa, long n, const double* Ua, const double* UaT, long m, int d, double sf2,
                         const TraceArgs& w, double* cpart, double* spart, double* cvec, double* out, long pan = 0, long pst = 0);

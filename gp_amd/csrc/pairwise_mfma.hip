@@ -127,7 +127,11 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_kernel(const MfmaPairArgs g) 
     using C = Cfg<KK>;
     __shared__ __attribute__((aligned(16))) double sU[C::DK * C::S1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;
-    const long a0 = (long)blockIdx.x * 128 + 32 * wv + 2 * l15;   // this lane's two rows: a0, a0 + 1
+    const bool vec = ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (g.ldo % 2 == 0) && (g.pst % 2 == 0);
+    // one 128-row block per workgroup, or (grid < nblk: a launch that must leave CUs empty for a chain of small kernels
+    // running beside it, sparse.hip) a stride over the row blocks
+    for (int blk = blockIdx.x; blk < g.nblk; blk += gridDim.x) {
+    const long a0 = (long)blk * 128 + 32 * wv + 2 * l15;   // this lane's two rows: a0, a0 + 1
     double xf[2][KK];
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
@@ -135,9 +139,8 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_kernel(const MfmaPairArgs g) 
         xf[0][kk] = x.x;
         xf[1][kk] = x.y;
     }
-    const bool rows_in = (long)blockIdx.x * 128 + 128 <= g.n;
-    double* const outb = g.out + panel_shift(g, (long)blockIdx.x * 128);
-    const bool vec = ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0) && (g.ldo % 2 == 0) && (g.pst % 2 == 0);
+    const bool rows_in = (long)blk * 128 + 128 <= g.n;
+    double* const outb = g.out + panel_shift(g, (long)blk * 128);
     for (long b0 = 0; b0 < g.m; b0 += C::TB) {
         __syncthreads();
         stage_u<KK, false>(g, b0, sU, nullptr);
@@ -166,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_kernel(const MfmaPairArgs g) 
                 }
             }
         }
+    }
     }
 }
 
@@ -1097,7 +1101,7 @@ int gpx_mfma_prepare(hipStream_t st, const double* Xt, long ldx, long n, const d
 }
 
 int gpx_mfma_cov_build(hipStream_t st, const double* Xa, long n, const double* Ua, long m, int d, double sf2, double* out,
-                       long ldo, long pan, long pst) {
+                       long ldo, long pan, long pst, int max_grid) {
     if (n <= 0 || m <= 0) return GPX_OK;
     if (pan % 128) return GPX_ERR_ARG;
     MfmaPairArgs g = {};
@@ -1107,8 +1111,10 @@ int gpx_mfma_cov_build(hipStream_t st, const double* Xa, long n, const double* U
     g.d = d; g.sf2 = sf2; g.out = out; g.ldo = ldo;
     const long nblk = (n + 127) / 128;
     if (nblk > 0x7fffffffL) return GPX_ERR_ARG;
+    g.nblk = (int)nblk;
+    const long grid = max_grid > 0 && max_grid < nblk ? max_grid : nblk;
     const long slot = gpx_pair_prof_open(st, 0, 8.0 * (double)n * (double)m);
-    GPX_KK_SWITCH(GPX_COV_K, kk_of(d), (unsigned)nblk, st, g);
+    GPX_KK_SWITCH(GPX_COV_K, kk_of(d), (unsigned)grid, st, g);
     gpx_pair_prof_close(st, slot);
     HIP_TRY(hipGetLastError());
     return GPX_OK;

@@ -241,6 +241,7 @@ struct Sparse {
     }
 
     bool mfma() const { return c->mfma_pairwise && gpx_mfma_pair_supported(d); }
+    int build_max_grid = 0;   // > 0: the Kxu build runs on at most that many workgroups (kernels(): the chain beside it)
     long nparts() const { return 2 * ((m + 127) / 128); }   // parts of the GEMM row-dot epilogue (gpx_internal.h)
     // V = Kxu Lu^-T with rowsum(V o V) from the epilogue, then Gamma (FITC.cpp:213-216)
     int v_and_gamma(const double* Winv_u, const double* r, double sn2, double sf2, double* g, double* p) {
@@ -354,7 +355,7 @@ struct Sparse {
         if (mfma()) {
             if ((rc = gpx_mfma_prepare(st, c->Xt.p, c->ldx, n, c->Ut.p, c->ldu, m, d, c->cen.p, c->Xa.p, c->Ua.p, c->UaT.p)))
                 return rc;
-            return gpx_mfma_cov_build(st, c->Xa.p, n, c->Ua.p, m, d, h.sf2, c->Kxu.p, ldk, pan, pst);
+            return gpx_mfma_cov_build(st, c->Xa.p, n, c->Ua.p, m, d, h.sf2, c->Kxu.p, ldk, pan, pst, build_max_grid);
         }
         return gpx_cov_build(st, c->Xt.p, c->ldx, n, c->Ut.p, c->ldu, m, c->dpad, h.sf2, c->Kxu.p, ldn, 0, 0.0);
     }
@@ -386,13 +387,22 @@ struct Sparse {
         HIP_TRY(hipMemsetAsync(c->info, 0, 2 * sizeof(int), st));
         if (fused_inverse) {
             hipStream_t sf = st;
+            // FITC on a small shard (the build shorter than the chain: the 8-GPU case): the build runs on at most 224
+            // workgroups.  At two workgroups per CU they occupy at most 224 of the 256 CUs however the dispatcher places
+            // them, so at least 32 CUs stay EMPTY for the chain (a base block needs a whole CU: 150 KB of LDS, every vector
+            // register) - the chain and the build then really run side by side, build first in the host's order.
+            static const int thr_env = [] { const char* e = getenv("GPX_BUILD_THROTTLE"); return e ? atoi(e) : -1; }();
+            const bool throttle = overlap && !defer_join && mfma() && (thr_env >= 0 ? thr_env > 0 : (double)n * (double)m <= 268435456.0);
             if (overlap) {
                 sf = c->st2;
                 HIP_TRY(hipEventRecord(c->ev[0], st));
                 HIP_TRY(hipStreamWaitEvent(sf, c->ev[0], 0));
                 if ((rc = gpx_scale_inputs(st, c->X.p, n, d, c->dpad, h.sc, c->Xt.p, c->ldx))) return rc;
-                if (defer_join) {   // VFE: the 25 ms build goes first (the chain's ~70 launches are host-bound)
-                    if ((rc = build_kxu())) return rc;
+                if (defer_join || throttle) {   // VFE: the 25 ms build goes first (the chain's ~70 launches are host-bound)
+                    build_max_grid = throttle ? (thr_env > 1 ? thr_env : 224) : 0;
+                    rc = build_kxu();
+                    build_max_grid = 0;
+                    if (rc) return rc;
                     if ((rc = gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p))) return rc;
                 }
             }
@@ -406,8 +416,10 @@ struct Sparse {
             if (overlap) {
                 if (!defer_join) {
                     HIP_TRY(hipEventRecord(c->ev[1], sf));
-                    if ((rc = build_kxu())) return rc;
-                    if ((rc = gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p))) return rc;
+                    if (!throttle) {
+                        if ((rc = build_kxu())) return rc;
+                        if ((rc = gpx_vec_shift(st, n, c->y.p, h.mean, 1.0, c->r.p))) return rc;
+                    }
                     HIP_TRY(hipStreamWaitEvent(st, c->ev[1], 0));
                 }
                 if (kuu_inv_behind) {
